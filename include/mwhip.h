@@ -1,0 +1,137 @@
+/* mwhip.h — C ABI of the MI355X (gfx950) Whisper transcription engine.
+ *
+ * The reference has no FFI: its boundary is three Python calls into the
+ * un-vendored `whisperx` package (reference transcribe.py:107-113 load_model,
+ * :117 load_audio, :123 model.transcribe).  This header is what a binding for
+ * that boundary talks to; each entry point names the call it stands behind.
+ * Audio decoding (load_audio) stays on the host and has no entry point here.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative mw_status; the message
+ *    of the last failure is available from mw_last_error().  Nothing throws or
+ *    aborts across this boundary.
+ *  - the caller owns every buffer it passes; the context owns all device
+ *    memory (weights, caches, workspaces, captured graph).
+ *  - a data pointer may be a host pointer or a device pointer of the
+ *    context's GPU; the library asks the HIP runtime which one it is.
+ *  - a context is bound to one GPU and one HIP stream and is not thread-safe;
+ *    separate contexts are independent.  Multi-GPU = one process per GPU.
+ *  - audio is float32 mono 16 kHz in [-1, 1); a chunk is 480000 samples (30 s).
+ */
+#ifndef MWHIP_H
+#define MWHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mw_ctx mw_ctx;
+
+typedef enum {
+    MW_OK = 0,
+    MW_ERR_ARG = -1,        /* bad argument (null, out of range, wrong shape)   */
+    MW_ERR_STATE = -2,      /* call order violated (e.g. decode before encode) */
+    MW_ERR_HIP = -3,        /* a HIP runtime call failed                        */
+    MW_ERR_NAME = -4,       /* unknown or duplicate weight name                 */
+    MW_ERR_MISSING = -5,    /* mw_finalize: a required weight was never set     */
+    MW_ERR_NOMEM = -6
+} mw_status;
+
+typedef enum { MW_F32 = 0, MW_F16 = 1, MW_BF16 = 2 } mw_dtype;
+
+/* Architecture of the checkpoint (what `MODEL_SIZE`, reference transcribe.py:33,
+ * resolves to inside whisperx.load_model). head_dim must be 64. */
+typedef struct {
+    int32_t n_mels;        /* 80 or 128 */
+    int32_t d_model;
+    int32_t n_heads;
+    int32_t enc_layers;
+    int32_t dec_layers;
+    int32_t ffn_dim;
+    int32_t vocab;
+    int32_t n_audio_ctx;   /* 1500 */
+    int32_t n_text_ctx;    /* 448  */
+} mw_model_desc;
+
+/* Decoding rules; the asr_options / language arguments of whisperx.load_model
+ * (reference transcribe.py:107-113) resolve to these. Arrays are copied. */
+typedef struct {
+    const int32_t* prompt;          int32_t n_prompt;          /* forced ids, >= 1            */
+    const int32_t* suppress;        int32_t n_suppress;        /* masked at every sampled step */
+    const int32_t* begin_suppress;  int32_t n_begin_suppress;  /* also masked at the first one */
+    int32_t eot;                                               /* end-of-text id               */
+    int32_t max_new;                                           /* sampled tokens per chunk     */
+} mw_decode_opts;
+
+/* ---- engine life cycle: whisperx.load_model (reference transcribe.py:107-113) ---- */
+
+/* Create an engine on GPU `device` able to process up to `max_batch` chunks per call. */
+int mw_create(const mw_model_desc* desc, int device, int max_batch, mw_ctx** out);
+
+/* Hand over one tensor of a Hugging Face-layout Whisper state dict
+ * ("model.encoder.conv1.weight", ...; "proj_out.weight" is accepted and ignored,
+ * it is tied to the token embedding).  The data is copied/converted at once. */
+int mw_set_weight(mw_ctx* ctx, const char* name, const void* data,
+                  const int64_t* shape, int ndim, int dtype);
+
+/* Check that every tensor arrived; builds derived tables. Must precede any compute. */
+int mw_finalize(mw_ctx* ctx);
+
+int mw_set_decode_opts(mw_ctx* ctx, const mw_decode_opts* opts);
+
+/* Free everything the context owns (reference transcribe.py:153-154 `del model`). */
+void mw_destroy(mw_ctx* ctx);
+
+/* Message of the most recent failure on this context (or of mw_create when ctx is NULL). */
+const char* mw_last_error(const mw_ctx* ctx);
+
+/* ---- the hot path: model.transcribe (reference transcribe.py:123) ---- */
+
+/* Stage 1: log-mel features of `batch` chunks. pcm: float32 [batch][480000].
+ * mel_out (optional): float32 [batch][n_mels][3000]. The features also stay in the
+ * context for mw_encode. */
+int mw_logmel(mw_ctx* ctx, const float* pcm, int batch, float* mel_out);
+
+/* Stage 2: encoder + per-layer cross-attention K/V for the decoder.
+ * mel (optional): float32 [batch][n_mels][3000] to use instead of the features left by
+ * mw_logmel. enc_out (optional): float32 [batch][n_audio_ctx][d_model]. */
+int mw_encode(mw_ctx* ctx, const float* mel, int batch, float* enc_out);
+
+/* Stage 3: greedy decoding of the chunks encoded last.
+ * out_ids: int32 [batch][max_new] (padded with eot); out_len: int32 [batch] = tokens
+ * before eot.  logits_out (optional): float32 [max_new][batch][vocab], the raw
+ * (unmasked) logits every sampled token was chosen from; rows after every chunk has
+ * finished are left untouched. */
+int mw_decode_greedy(mw_ctx* ctx, int batch, int32_t* out_ids, int32_t* out_len, float* logits_out);
+
+/* Teacher-forced decoder pass over given ids (parity checks): tokens int32 [batch][n];
+ * logits_out float32 [batch][n][vocab]. */
+int mw_decode_forced(mw_ctx* ctx, int batch, const int32_t* tokens, int n, float* logits_out);
+
+/* Stages 1-3 in one call: pcm float32 [batch][480000] -> ids. */
+int mw_transcribe_batch(mw_ctx* ctx, const float* pcm, int batch, int32_t* out_ids, int32_t* out_len);
+
+/* ---- measurement ---- */
+
+/* GPU time in ms of the last call's stages, from HIP events on the context's stream:
+ * [0] log-mel  [1] encoder  [2] cross K/V  [3] decode loop  [4] number of decode steps
+ * [5] mean duration of the cross-attention decode kernel over the loop's steps is NOT here:
+ * see mw_profile_cross_attention. */
+int mw_stage_ms(mw_ctx* ctx, float out[5]);
+
+/* Re-run only the decode-time cross-attention kernel of layer 0 `iters` times on the
+ * current caches and report its mean duration (ms) and the bytes it must read per launch. */
+int mw_profile_cross_attention(mw_ctx* ctx, int batch, int iters, float* mean_ms, double* bytes_per_launch);
+
+/* Engine options: key "graph" (1 = capture the decode step into a hipGraph, default 1),
+ * "check_every" (decode steps between host checks for all-finished, default 16). */
+int mw_set_option(mw_ctx* ctx, const char* key, int value);
+
+int mw_synchronize(mw_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MWHIP_H */

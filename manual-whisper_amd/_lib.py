@@ -1,0 +1,67 @@
+"""ctypes binding of libmwhip.so (declared in include/mwhip.h).
+
+There is no CPU fallback: if the library is missing or cannot be loaded the
+import error says how to build it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmwhip.so")
+
+# every symbol include/mwhip.h declares
+SYMBOLS = (
+    "mw_create", "mw_set_weight", "mw_finalize", "mw_set_decode_opts", "mw_destroy", "mw_last_error",
+    "mw_logmel", "mw_encode", "mw_decode_greedy", "mw_decode_forced", "mw_transcribe_batch",
+    "mw_stage_ms", "mw_profile_cross_attention", "mw_set_option", "mw_synchronize",
+)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_mels", "d_model", "n_heads", "enc_layers", "dec_layers",
+                                          "ffn_dim", "vocab", "n_audio_ctx", "n_text_ctx")]
+
+
+class DecodeOpts(C.Structure):
+    _fields_ = [("prompt", C.POINTER(C.c_int32)), ("n_prompt", C.c_int32),
+                ("suppress", C.POINTER(C.c_int32)), ("n_suppress", C.c_int32),
+                ("begin_suppress", C.POINTER(C.c_int32)), ("n_begin_suppress", C.c_int32),
+                ("eot", C.c_int32), ("max_new", C.c_int32)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m manual_whisper_amd.build` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p
+    lib.mw_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.c_int, C.POINTER(vp)]
+    lib.mw_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int, C.c_int]
+    lib.mw_finalize.argtypes = [vp]
+    lib.mw_set_decode_opts.argtypes = [vp, C.POINTER(DecodeOpts)]
+    lib.mw_destroy.argtypes = [vp]
+    lib.mw_destroy.restype = None
+    lib.mw_last_error.argtypes = [vp]
+    lib.mw_last_error.restype = C.c_char_p
+    lib.mw_logmel.argtypes = [vp, f32p, C.c_int, f32p]
+    lib.mw_encode.argtypes = [vp, f32p, C.c_int, f32p]
+    lib.mw_decode_greedy.argtypes = [vp, C.c_int, vp, vp, f32p]
+    lib.mw_decode_forced.argtypes = [vp, C.c_int, vp, C.c_int, f32p]
+    lib.mw_transcribe_batch.argtypes = [vp, f32p, C.c_int, vp, vp]
+    lib.mw_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.mw_profile_cross_attention.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+    lib.mw_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.mw_synchronize.argtypes = [vp]
+    for name in SYMBOLS:
+        if name not in ("mw_destroy", "mw_last_error"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib

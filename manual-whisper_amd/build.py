@@ -1,0 +1,72 @@
+"""Build libmwhip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m manual_whisper_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The library is never built at import or
+inside a test: it is built ahead of time and travels with the tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmwhip.so")
+SOURCES = ["engine.hip", "kernels_mel.hip", "kernels_gemm.hip", "kernels_enc.hip", "kernels_dec.hip"]
+HEADERS = [os.path.join(CSRC, "mw_kernels.h"), os.path.join(os.path.dirname(HERE), "include", "mwhip.h")]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; cannot build libmwhip.so")
+    return exe
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = True) -> str:
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if out.strip() and verbose:
+            print(out)
+        if p.returncode != 0:
+            failed = True
+            print(f"hipcc failed on {src}", file=sys.stderr)
+            if not verbose:
+                print(out, file=sys.stderr)
+    if failed:
+        raise RuntimeError("building libmwhip.so failed")
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv))

@@ -1,0 +1,852 @@
+// Engine behind the C ABI of include/mwhip.h: owns the weights, workspaces and K/V caches of one
+// GPU, sequences the kernels of the hot path (log-mel -> encoder -> cross K/V -> greedy decode) on
+// one HIP stream, and replays a captured hipGraph of one decode step per token.
+#include "../../include/mwhip.h"
+#include "mw_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+using namespace mw;
+
+static thread_local std::string g_create_error;
+
+struct LinearW { f16* w = nullptr; float* b = nullptr; };
+struct NormW { float* g = nullptr; float* b = nullptr; };
+
+struct EncLayerW { NormW ln1, ln2; LinearW qkv, out, fc1, fc2; };
+struct DecLayerW { NormW ln1, ln2, ln3; LinearW qkv, out, cq, co, fc1, fc2; };
+
+struct mw_ctx {
+    mw_model_desc d{};
+    int device = 0, max_batch = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void*> allocs;
+    bool finalized = false;
+    int use_graph = 1, check_every = 16;
+
+    // weights
+    f16* conv1_w = nullptr; float* conv1_b = nullptr;     // [D][3][n_mels]
+    f16* conv2_w = nullptr; float* conv2_b = nullptr;     // [D][3][D]
+    float* enc_pos = nullptr;                             // [1500][D] fp32
+    std::vector<EncLayerW> enc;
+    NormW enc_ln;
+    f16* tok_emb = nullptr; f16* dec_pos = nullptr;
+    std::vector<DecLayerW> dec;
+    NormW dec_ln;
+    f16* ckv_w = nullptr; float* ckv_b = nullptr;         // [L][2D][D], [L][2D] (k part of the bias = 0)
+    std::set<std::string> seen;
+    bool enc_pos_set = false;
+
+    // mel tables
+    float *basis_cos = nullptr, *basis_sin = nullptr, *filt = nullptr;
+    int n_mels_pad = 0;
+
+    // staging for host -> device weight import
+    void* stage = nullptr; size_t stage_bytes = 0;
+
+    // encoder workspaces (sized for max_batch)
+    float* pcm_dev = nullptr;
+    float* logmel = nullptr; float* blockmax = nullptr;
+    f16* melT = nullptr; f16* h1 = nullptr;
+    float* x = nullptr; f16* xn = nullptr;
+    f16 *q = nullptr, *k = nullptr, *vT = nullptr, *att = nullptr, *hid = nullptr, *enc_out = nullptr;
+    float* enc_out32 = nullptr;
+    f16 *crossK = nullptr, *crossV = nullptr;             // [L][B][H][1500][64]
+    int Tpad = 0;
+    int mel_batch = 0, enc_batch = 0;
+
+    // decoder workspaces
+    DecState* st = nullptr;
+    float* dx = nullptr; f16 *dq = nullptr, *datt = nullptr, *dhid = nullptr, *dxn = nullptr;
+    f16 *selfK = nullptr, *selfV = nullptr;               // [L][B][H][n_text_ctx][64]
+    float* logits = nullptr; float* part_val = nullptr; int* part_idx = nullptr; int n_parts = 0;
+    uint8_t *mask_first = nullptr, *mask_rest = nullptr;
+    int *forced = nullptr, *out_ids = nullptr, *out_len = nullptr, *finished = nullptr;
+    int forced_cap = 0;
+
+    // decode options
+    std::vector<int32_t> prompt;
+    int eot = 0, max_new = 0;
+    bool opts_set = false;
+
+    // captured decode step
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; int graph_batch = 0; int graph_logits = -1;
+
+    // timing
+    hipEvent_t ev[6]{};
+    float stage_ms[5]{};
+};
+
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            char buf_[512];                                                                       \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            ctx->err = buf_;                                                                      \
+            return MW_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+static int fail(mw_ctx* ctx, int code, const std::string& msg) {
+    ctx->err = msg;
+    return code;
+}
+
+template <typename T>
+static int dalloc(mw_ctx* ctx, T** out, size_t count, bool zero = false) {
+    void* p = nullptr;
+    const size_t bytes = count * sizeof(T) + 256;     // slack: vector loads may run a few bytes past a tail
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e);
+        return MW_ERR_NOMEM;
+    }
+    ctx->allocs.push_back(p);
+    if (zero) {
+        e = hipMemsetAsync(p, 0, bytes, ctx->stream);
+        if (e != hipSuccess) { ctx->err = "hipMemsetAsync failed"; return MW_ERR_HIP; }
+    }
+    *out = reinterpret_cast<T*>(p);
+    return MW_OK;
+}
+#define ALLOC(ptr, count, ...)                                          \
+    do { int r_ = dalloc(ctx, &(ptr), (count), ##__VA_ARGS__); if (r_) return r_; } while (0)
+
+static bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// ---------------------------------------------------------------------------------------------
+// creation
+// ---------------------------------------------------------------------------------------------
+static int build_mel_tables(mw_ctx* ctx) {
+    const int n_mels = ctx->d.n_mels;
+    ctx->n_mels_pad = ((n_mels + 31) / 32) * 32;
+    std::vector<float> bc((size_t)kNfft * kFreqPad, 0.f), bs((size_t)kNfft * kFreqPad, 0.f);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int n = 0; n < kNfft; ++n) {
+        const double w = 0.5 - 0.5 * cos(two_pi * n / kNfft);          // periodic Hann (torch.hann_window)
+        for (int f = 0; f <= kNfft / 2; ++f) {
+            const int r = (int)(((long)f * n) % kNfft);                 // exact angle reduction
+            const double a = two_pi * r / kNfft;
+            bc[(size_t)n * kFreqPad + f] = (float)(w * cos(a));
+            bs[(size_t)n * kFreqPad + f] = (float)(-w * sin(a));
+        }
+    }
+    // slaney mel scale + slaney normalisation, 0..8000 Hz (transformers audio_utils.py:638-729)
+    auto hz_to_mel = [](double f) { return f >= 1000.0 ? 15.0 + log(f / 1000.0) * (27.0 / log(6.4)) : 3.0 * f / 200.0; };
+    auto mel_to_hz = [](double m) { return m >= 15.0 ? 1000.0 * exp((log(6.4) / 27.0) * (m - 15.0)) : 200.0 * m / 3.0; };
+    std::vector<double> pts(n_mels + 2);
+    const double m_lo = hz_to_mel(0.0), m_hi = hz_to_mel(8000.0);
+    for (int i = 0; i < n_mels + 2; ++i) pts[i] = mel_to_hz(m_lo + (m_hi - m_lo) * i / (n_mels + 1));
+    std::vector<float> fl((size_t)kFreqPad * ctx->n_mels_pad, 0.f);
+    for (int f = 0; f <= kNfft / 2; ++f) {
+        const double hz = 8000.0 * f / (kNfft / 2);
+        for (int m = 0; m < n_mels; ++m) {
+            const double down = (hz - pts[m]) / (pts[m + 1] - pts[m]);
+            const double up = (pts[m + 2] - hz) / (pts[m + 2] - pts[m + 1]);
+            double v = fmin(down, up);
+            if (v < 0) v = 0;
+            v *= 2.0 / (pts[m + 2] - pts[m]);
+            fl[(size_t)f * ctx->n_mels_pad + m] = (float)v;
+        }
+    }
+    ALLOC(ctx->basis_cos, bc.size());
+    ALLOC(ctx->basis_sin, bs.size());
+    ALLOC(ctx->filt, fl.size());
+    HIPCHK(hipMemcpy(ctx->basis_cos, bc.data(), bc.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->basis_sin, bs.data(), bs.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->filt, fl.data(), fl.size() * 4, hipMemcpyHostToDevice));
+    return MW_OK;
+}
+
+static int alloc_all(mw_ctx* ctx) {
+    const mw_model_desc& d = ctx->d;
+    const size_t D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, B = ctx->max_batch;
+    const size_t M = B * T;
+    ctx->Tpad = (int)((T + 7) / 8 * 8);
+    // weights
+    ALLOC(ctx->conv1_w, D * 3 * d.n_mels); ALLOC(ctx->conv1_b, D);
+    ALLOC(ctx->conv2_w, D * 3 * D); ALLOC(ctx->conv2_b, D);
+    ALLOC(ctx->enc_pos, T * D);
+    ctx->enc.resize(d.enc_layers);
+    for (auto& l : ctx->enc) {
+        ALLOC(l.ln1.g, D); ALLOC(l.ln1.b, D); ALLOC(l.ln2.g, D); ALLOC(l.ln2.b, D);
+        ALLOC(l.qkv.w, 3 * D * D); ALLOC(l.qkv.b, 3 * D, true);
+        ALLOC(l.out.w, D * D); ALLOC(l.out.b, D);
+        ALLOC(l.fc1.w, F * D); ALLOC(l.fc1.b, F);
+        ALLOC(l.fc2.w, D * F); ALLOC(l.fc2.b, D);
+    }
+    ALLOC(ctx->enc_ln.g, D); ALLOC(ctx->enc_ln.b, D);
+    ALLOC(ctx->tok_emb, (size_t)d.vocab * D);
+    ALLOC(ctx->dec_pos, (size_t)d.n_text_ctx * D);
+    ctx->dec.resize(d.dec_layers);
+    for (auto& l : ctx->dec) {
+        ALLOC(l.ln1.g, D); ALLOC(l.ln1.b, D); ALLOC(l.ln2.g, D); ALLOC(l.ln2.b, D); ALLOC(l.ln3.g, D); ALLOC(l.ln3.b, D);
+        ALLOC(l.qkv.w, 3 * D * D); ALLOC(l.qkv.b, 3 * D, true);
+        ALLOC(l.out.w, D * D); ALLOC(l.out.b, D);
+        ALLOC(l.cq.w, D * D); ALLOC(l.cq.b, D);
+        ALLOC(l.co.w, D * D); ALLOC(l.co.b, D);
+        ALLOC(l.fc1.w, F * D); ALLOC(l.fc1.b, F);
+        ALLOC(l.fc2.w, D * F); ALLOC(l.fc2.b, D);
+    }
+    ALLOC(ctx->dec_ln.g, D); ALLOC(ctx->dec_ln.b, D);
+    ALLOC(ctx->ckv_w, (size_t)d.dec_layers * 2 * D * D); ALLOC(ctx->ckv_b, (size_t)d.dec_layers * 2 * D, true);
+    // encoder workspaces
+    ALLOC(ctx->pcm_dev, B * (size_t)kChunkSamples);
+    ALLOC(ctx->logmel, B * (size_t)d.n_mels * kFrames);
+    ALLOC(ctx->blockmax, B * 128);
+    ALLOC(ctx->melT, B * (size_t)(kFrames + 2) * d.n_mels, true);
+    ALLOC(ctx->h1, B * (size_t)(kFrames + 2) * D, true);
+    ALLOC(ctx->x, M * D); ALLOC(ctx->xn, M * D);
+    ALLOC(ctx->q, M * D); ALLOC(ctx->k, M * D);
+    ALLOC(ctx->vT, B * H * 64 * (size_t)ctx->Tpad, true);
+    ALLOC(ctx->att, M * D); ALLOC(ctx->hid, M * F);
+    ALLOC(ctx->enc_out, M * D); ALLOC(ctx->enc_out32, M * D);
+    ALLOC(ctx->crossK, (size_t)d.dec_layers * M * D);
+    ALLOC(ctx->crossV, (size_t)d.dec_layers * M * D);
+    // decoder workspaces
+    ALLOC(ctx->st, 1, true);
+    ALLOC(ctx->dx, B * D); ALLOC(ctx->dq, B * D); ALLOC(ctx->datt, B * D); ALLOC(ctx->dhid, B * F); ALLOC(ctx->dxn, B * D);
+    ALLOC(ctx->selfK, (size_t)d.dec_layers * B * D * d.n_text_ctx, true);
+    ALLOC(ctx->selfV, (size_t)d.dec_layers * B * D * d.n_text_ctx, true);
+    ALLOC(ctx->logits, B * (size_t)d.vocab);
+    ctx->n_parts = gemv_logits_parts(d.vocab);
+    ALLOC(ctx->part_val, B * (size_t)ctx->n_parts); ALLOC(ctx->part_idx, B * (size_t)ctx->n_parts);
+    ALLOC(ctx->mask_first, (size_t)d.vocab, true); ALLOC(ctx->mask_rest, (size_t)d.vocab, true);
+    ctx->forced_cap = d.n_text_ctx;
+    ALLOC(ctx->forced, B * (size_t)ctx->forced_cap);
+    ALLOC(ctx->out_ids, B * (size_t)d.n_text_ctx); ALLOC(ctx->out_len, B); ALLOC(ctx->finished, B);
+    return MW_OK;
+}
+
+extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, mw_ctx** out) {
+    if (!desc || !out) { g_create_error = "mw_create: null argument"; return MW_ERR_ARG; }
+    *out = nullptr;
+    const mw_model_desc& d = *desc;
+    if (d.d_model <= 0 || d.n_heads <= 0 || d.d_model != d.n_heads * kHeadDim) { g_create_error = "mw_create: head_dim must be 64"; return MW_ERR_ARG; }
+    if (d.d_model % 32 || d.ffn_dim % 32 || d.d_model > 2048) { g_create_error = "mw_create: d_model/ffn_dim must be multiples of 32, d_model <= 2048"; return MW_ERR_ARG; }
+    if (d.n_mels % 8 || d.n_mels > 128 || d.n_mels <= 0) { g_create_error = "mw_create: n_mels must be a multiple of 8, <= 128"; return MW_ERR_ARG; }
+    if (d.n_audio_ctx != kFrames / 2 || d.n_text_ctx <= 0 || d.n_text_ctx > 448) { g_create_error = "mw_create: n_audio_ctx must be 1500 and n_text_ctx <= 448"; return MW_ERR_ARG; }
+    if (max_batch < 1 || max_batch > 32) { g_create_error = "mw_create: max_batch must be in 1..32"; return MW_ERR_ARG; }
+    if (d.vocab < 16 || d.enc_layers < 1 || d.dec_layers < 1) { g_create_error = "mw_create: bad vocab/layer count"; return MW_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        g_create_error = "mw_create: no such HIP device " + std::to_string(device) + " (" + std::to_string(ndev) + " visible)";
+        return MW_ERR_HIP;
+    }
+    mw_ctx* ctx = new mw_ctx();
+    ctx->d = d; ctx->device = device; ctx->max_batch = max_batch;
+    auto bail = [&](int code) { g_create_error = ctx->err; mw_destroy(ctx); return code; };
+    if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(MW_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(MW_ERR_HIP); }
+    for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(MW_ERR_HIP); }
+    int r = alloc_all(ctx);
+    if (r) return bail(r);
+    r = build_mel_tables(ctx);
+    if (r) return bail(r);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "stream sync failed in mw_create"; return bail(MW_ERR_HIP); }
+    *out = ctx;
+    return MW_OK;
+}
+
+extern "C" void mw_destroy(mw_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
+    for (void* p : ctx->allocs) (void)hipFree(p);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* mw_last_error(const mw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int mw_set_option(mw_ctx* ctx, const char* key, int value) {
+    if (!ctx || !key) return MW_ERR_ARG;
+    if (!strcmp(key, "graph")) ctx->use_graph = value != 0;
+    else if (!strcmp(key, "check_every")) ctx->check_every = value < 1 ? 1 : value;
+    else return fail(ctx, MW_ERR_ARG, std::string("mw_set_option: unknown key ") + key);
+    return MW_OK;
+}
+
+extern "C" int mw_synchronize(mw_ctx* ctx) {
+    if (!ctx) return MW_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------------------
+struct Slot { void* dst; long count; int to_f16; int conv_c; };   // conv_c > 0: permute [D][C][3] -> [D][3][C]
+
+static bool resolve(mw_ctx* ctx, const std::string& name, Slot* s, std::vector<int64_t>* shape) {
+    const mw_model_desc& d = ctx->d;
+    const long D = d.d_model, F = d.ffn_dim;
+    auto mat = [&](f16* p, long r, long c) { *s = {p, r * c, 1, 0}; *shape = {r, c}; return true; };
+    auto vec = [&](float* p, long n) { *s = {p, n, 0, 0}; *shape = {n}; return true; };
+    auto norm = [&](NormW& n, const std::string& leaf) {
+        if (leaf == "weight") return vec(n.g, D);
+        if (leaf == "bias") return vec(n.b, D);
+        return false;
+    };
+    if (name == "model.encoder.conv1.weight") { *s = {ctx->conv1_w, D * d.n_mels * 3, 1, d.n_mels}; *shape = {D, d.n_mels, 3}; return true; }
+    if (name == "model.encoder.conv1.bias") return vec(ctx->conv1_b, D);
+    if (name == "model.encoder.conv2.weight") { *s = {ctx->conv2_w, D * D * 3, 1, (int)D}; *shape = {D, D, 3}; return true; }
+    if (name == "model.encoder.conv2.bias") return vec(ctx->conv2_b, D);
+    if (name == "model.encoder.embed_positions.weight") { *s = {ctx->enc_pos, (long)d.n_audio_ctx * D, 0, 0}; *shape = {d.n_audio_ctx, D}; return true; }
+    if (name == "model.encoder.layer_norm.weight") return vec(ctx->enc_ln.g, D);
+    if (name == "model.encoder.layer_norm.bias") return vec(ctx->enc_ln.b, D);
+    if (name == "model.decoder.embed_tokens.weight") return mat(ctx->tok_emb, d.vocab, D);
+    if (name == "model.decoder.embed_positions.weight") return mat(ctx->dec_pos, d.n_text_ctx, D);
+    if (name == "model.decoder.layer_norm.weight") return vec(ctx->dec_ln.g, D);
+    if (name == "model.decoder.layer_norm.bias") return vec(ctx->dec_ln.b, D);
+
+    const bool is_enc = name.rfind("model.encoder.layers.", 0) == 0;
+    const bool is_dec = name.rfind("model.decoder.layers.", 0) == 0;
+    if (!is_enc && !is_dec) return false;
+    const size_t p0 = strlen("model.encoder.layers.");
+    const size_t p1 = name.find('.', p0);
+    if (p1 == std::string::npos) return false;
+    int li = 0;
+    for (size_t i = p0; i < p1; ++i) { if (name[i] < '0' || name[i] > '9') return false; li = li * 10 + (name[i] - '0'); }
+    if (li >= (is_enc ? d.enc_layers : d.dec_layers)) return false;
+    const std::string rest = name.substr(p1 + 1);
+    const size_t dot = rest.rfind('.');
+    if (dot == std::string::npos) return false;
+    const std::string mod = rest.substr(0, dot), leaf = rest.substr(dot + 1);
+    const bool isw = leaf == "weight", isb = leaf == "bias";
+    if (!isw && !isb) return false;
+
+    auto proj = [&](LinearW& qkv, LinearW& out, const std::string& pj) {
+        int sec = pj == "q_proj" ? 0 : pj == "k_proj" ? 1 : pj == "v_proj" ? 2 : pj == "out_proj" ? 3 : -1;
+        if (sec < 0) return false;
+        if (sec == 3) return isw ? mat(out.w, D, D) : vec(out.b, D);
+        if (sec == 1 && isb) return false;                             // k_proj has no bias (modeling_whisper.py:279)
+        return isw ? mat(qkv.w + sec * D * D, D, D) : vec(qkv.b + sec * D, D);
+    };
+    auto fc = [&](LinearW& l, long o, long i) { return isw ? mat(l.w, o, i) : vec(l.b, o); };
+
+    if (is_enc) {
+        EncLayerW& l = ctx->enc[li];
+        if (mod.rfind("self_attn.", 0) == 0) return proj(l.qkv, l.out, mod.substr(10));
+        if (mod == "self_attn_layer_norm") return norm(l.ln1, leaf);
+        if (mod == "final_layer_norm") return norm(l.ln2, leaf);
+        if (mod == "fc1") return fc(l.fc1, F, D);
+        if (mod == "fc2") return fc(l.fc2, D, F);
+        return false;
+    }
+    DecLayerW& l = ctx->dec[li];
+    if (mod.rfind("self_attn.", 0) == 0) return proj(l.qkv, l.out, mod.substr(10));
+    if (mod.rfind("encoder_attn.", 0) == 0) {
+        const std::string pj = mod.substr(13);
+        if (pj == "q_proj") return isw ? mat(l.cq.w, D, D) : vec(l.cq.b, D);
+        if (pj == "out_proj") return isw ? mat(l.co.w, D, D) : vec(l.co.b, D);
+        if (pj == "k_proj") { if (isb) return false; return mat(ctx->ckv_w + (long)li * 2 * D * D, D, D); }
+        if (pj == "v_proj") return isw ? mat(ctx->ckv_w + (long)li * 2 * D * D + D * D, D, D) : vec(ctx->ckv_b + (long)li * 2 * D + D, D);
+        return false;
+    }
+    if (mod == "self_attn_layer_norm") return norm(l.ln1, leaf);
+    if (mod == "encoder_attn_layer_norm") return norm(l.ln2, leaf);
+    if (mod == "final_layer_norm") return norm(l.ln3, leaf);
+    if (mod == "fc1") return fc(l.fc1, F, D);
+    if (mod == "fc2") return fc(l.fc2, D, F);
+    return false;
+}
+
+extern "C" int mw_set_weight(mw_ctx* ctx, const char* name_c, const void* data, const int64_t* shape, int ndim, int dtype) {
+    if (!ctx) return MW_ERR_ARG;
+    if (!name_c || !data || !shape || ndim < 1 || ndim > 3) return fail(ctx, MW_ERR_ARG, "mw_set_weight: null or bad argument");
+    if (dtype < MW_F32 || dtype > MW_BF16) return fail(ctx, MW_ERR_ARG, "mw_set_weight: dtype must be MW_F32, MW_F16 or MW_BF16");
+    const std::string name(name_c);
+    if (name == "proj_out.weight") return MW_OK;                     // tied to embed_tokens
+    Slot s; std::vector<int64_t> want;
+    if (!resolve(ctx, name, &s, &want)) return fail(ctx, MW_ERR_NAME, "mw_set_weight: unknown tensor name '" + name + "'");
+    if ((int)want.size() != ndim) return fail(ctx, MW_ERR_ARG, "mw_set_weight: wrong rank for '" + name + "'");
+    for (int i = 0; i < ndim; ++i)
+        if (want[i] != shape[i]) return fail(ctx, MW_ERR_ARG, "mw_set_weight: wrong shape for '" + name + "' (dim " + std::to_string(i) + ": got " + std::to_string(shape[i]) + ", want " + std::to_string(want[i]) + ")");
+    if (!ctx->seen.insert(name).second) return fail(ctx, MW_ERR_NAME, "mw_set_weight: '" + name + "' set twice");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t esz = dtype == MW_F32 ? 4 : 2;
+    const void* src = data;
+    if (!is_device_ptr(data)) {
+        const size_t bytes = (size_t)s.count * esz;
+        if (bytes > ctx->stage_bytes) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (ctx->stage) (void)hipFree(ctx->stage);
+            ctx->stage = nullptr; ctx->stage_bytes = 0;
+            HIPCHK(hipMalloc(&ctx->stage, bytes));
+            ctx->stage_bytes = bytes;
+        }
+        HIPCHK(hipStreamSynchronize(ctx->stream));                  // previous conversion may still read the stage
+        HIPCHK(hipMemcpy(ctx->stage, data, bytes, hipMemcpyHostToDevice));
+        src = ctx->stage;
+    }
+    if (s.conv_c > 0) launch_conv_permute(src, dtype, reinterpret_cast<f16*>(s.dst), (int)want[0], s.conv_c, ctx->stream);
+    else launch_convert(src, dtype, s.dst, s.to_f16, s.count, ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));                      // the caller may free `data` on return
+    if (name == "model.encoder.embed_positions.weight") ctx->enc_pos_set = true;
+    return MW_OK;
+}
+
+extern "C" int mw_finalize(mw_ctx* ctx) {
+    if (!ctx) return MW_ERR_ARG;
+    const mw_model_desc& d = ctx->d;
+    std::vector<std::string> need = {"model.encoder.conv1.weight", "model.encoder.conv1.bias", "model.encoder.conv2.weight",
+                                     "model.encoder.conv2.bias", "model.encoder.layer_norm.weight", "model.encoder.layer_norm.bias",
+                                     "model.decoder.embed_tokens.weight", "model.decoder.embed_positions.weight",
+                                     "model.decoder.layer_norm.weight", "model.decoder.layer_norm.bias"};
+    auto attn = [&](const std::string& p) {
+        for (const char* pj : {"q_proj", "v_proj", "out_proj"}) { need.push_back(p + "." + pj + ".weight"); need.push_back(p + "." + pj + ".bias"); }
+        need.push_back(p + ".k_proj.weight");
+    };
+    auto two = [&](const std::string& p) { need.push_back(p + ".weight"); need.push_back(p + ".bias"); };
+    for (int i = 0; i < d.enc_layers; ++i) {
+        const std::string p = "model.encoder.layers." + std::to_string(i);
+        attn(p + ".self_attn"); two(p + ".self_attn_layer_norm"); two(p + ".final_layer_norm"); two(p + ".fc1"); two(p + ".fc2");
+    }
+    for (int i = 0; i < d.dec_layers; ++i) {
+        const std::string p = "model.decoder.layers." + std::to_string(i);
+        attn(p + ".self_attn"); attn(p + ".encoder_attn");
+        two(p + ".self_attn_layer_norm"); two(p + ".encoder_attn_layer_norm"); two(p + ".final_layer_norm"); two(p + ".fc1"); two(p + ".fc2");
+    }
+    for (const auto& n : need)
+        if (!ctx->seen.count(n)) return fail(ctx, MW_ERR_MISSING, "mw_finalize: weight '" + n + "' was never set");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->enc_pos_set) {     // sinusoid table (modeling_whisper.py:55-64): sin half then cos half
+        const int T = d.n_audio_ctx, D = d.d_model, half = D / 2;
+        std::vector<float> tab((size_t)T * D);
+        const double inc = log(10000.0) / (half - 1);
+        for (int t = 0; t < T; ++t)
+            for (int c = 0; c < half; ++c) {
+                const float inv = expf((float)(-inc * c));
+                const float a = (float)t * inv;
+                tab[(size_t)t * D + c] = sinf(a);
+                tab[(size_t)t * D + half + c] = cosf(a);
+            }
+        HIPCHK(hipMemcpy(ctx->enc_pos, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (ctx->stage) { (void)hipFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+    ctx->finalized = true;
+    return MW_OK;
+}
+
+extern "C" int mw_set_decode_opts(mw_ctx* ctx, const mw_decode_opts* o) {
+    if (!ctx) return MW_ERR_ARG;
+    if (!o || !o->prompt || o->n_prompt < 1) return fail(ctx, MW_ERR_ARG, "mw_set_decode_opts: a prompt of at least one id is required");
+    const int V = ctx->d.vocab;
+    if (o->max_new < 1 || o->n_prompt + o->max_new > ctx->d.n_text_ctx)
+        return fail(ctx, MW_ERR_ARG, "mw_set_decode_opts: n_prompt + max_new must fit n_text_ctx");
+    if (o->eot < 0 || o->eot >= V) return fail(ctx, MW_ERR_ARG, "mw_set_decode_opts: eot out of range");
+    auto in_range = [&](const int32_t* a, int n) { for (int i = 0; i < n; ++i) if (a[i] < 0 || a[i] >= V) return false; return true; };
+    if (!in_range(o->prompt, o->n_prompt) || (o->n_suppress && (!o->suppress || !in_range(o->suppress, o->n_suppress))) ||
+        (o->n_begin_suppress && (!o->begin_suppress || !in_range(o->begin_suppress, o->n_begin_suppress))))
+        return fail(ctx, MW_ERR_ARG, "mw_set_decode_opts: token id out of range");
+    std::vector<uint8_t> rest(V, 0), first;
+    for (int i = 0; i < o->n_suppress; ++i) rest[o->suppress[i]] = 1;
+    first = rest;
+    for (int i = 0; i < o->n_begin_suppress; ++i) first[o->begin_suppress[i]] = 1;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(ctx->mask_rest, rest.data(), V, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->mask_first, first.data(), V, hipMemcpyHostToDevice));
+    ctx->prompt.assign(o->prompt, o->prompt + o->n_prompt);
+    ctx->eot = o->eot; ctx->max_new = o->max_new; ctx->opts_set = true;
+    return MW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hot path
+// ---------------------------------------------------------------------------------------------
+static int check_batch(mw_ctx* ctx, int batch, const char* who) {
+    if (!ctx->finalized) return fail(ctx, MW_ERR_STATE, std::string(who) + ": mw_finalize has not succeeded yet");
+    if (batch < 1 || batch > ctx->max_batch) return fail(ctx, MW_ERR_ARG, std::string(who) + ": batch must be in 1.." + std::to_string(ctx->max_batch));
+    return MW_OK;
+}
+
+static int run_logmel(mw_ctx* ctx, const float* pcm_dev, int B) {
+    MelTables t{ctx->basis_cos, ctx->basis_sin, ctx->filt, ctx->d.n_mels, ctx->n_mels_pad};
+    launch_mel_dft(pcm_dev, B, t, ctx->logmel, ctx->blockmax, ctx->stream);
+    launch_mel_norm(ctx->logmel, ctx->blockmax, B, ctx->d.n_mels, ctx->melT, ctx->stream);
+    HIPCHK(hipGetLastError());
+    ctx->mel_batch = B;
+    return MW_OK;
+}
+
+extern "C" int mw_logmel(mw_ctx* ctx, const float* pcm, int batch, float* mel_out) {
+    if (!ctx) return MW_ERR_ARG;
+    int r = check_batch(ctx, batch, "mw_logmel");
+    if (r) return r;
+    if (!pcm) return fail(ctx, MW_ERR_ARG, "mw_logmel: pcm is null");
+    HIPCHK(hipSetDevice(ctx->device));
+    const float* src = pcm;
+    if (!is_device_ptr(pcm)) {
+        HIPCHK(hipMemcpyAsync(ctx->pcm_dev, pcm, (size_t)batch * kChunkSamples * 4, hipMemcpyHostToDevice, ctx->stream));
+        src = ctx->pcm_dev;
+    }
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    r = run_logmel(ctx, src, batch);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (mel_out)
+        HIPCHK(hipMemcpyAsync(mel_out, ctx->logmel, (size_t)batch * ctx->d.n_mels * kFrames * 4, hipMemcpyDefault, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventElapsedTime(&ctx->stage_ms[0], ctx->ev[0], ctx->ev[1]));
+    return MW_OK;
+}
+
+static GemmParams gemm_base(const f16* A, long lda, const f16* W, long ldw, int M, int N, int K, const float* bias) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.a_rows_per_batch = M > 0 ? M : 1; p.a_batch_stride = 0;
+    p.W = W; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.bias = bias;
+    p.scale = 1.f; p.scale_ncols = 0; p.gelu = 0; p.out_mode = OUT_F16;
+    p.c_rows_per_batch = M > 0 ? M : 1; p.c_batch_stride = 0;
+    return p;
+}
+
+static int run_encoder(mw_ctx* ctx, int B) {
+    const mw_model_desc& d = ctx->d;
+    const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, C = d.n_mels;
+    const int M = B * T;
+    hipStream_t s = ctx->stream;
+    const float qscale = 1.0f / sqrtf((float)kHeadDim);
+    // conv1 + GELU: rows are frames; A row (b,t) = melT[b][t .. t+2][:] (3*C contiguous halfs)
+    {
+        GemmParams p = gemm_base(ctx->melT, C, ctx->conv1_w, 3 * C, B * kFrames, D, 3 * C, ctx->conv1_b);
+        p.a_rows_per_batch = kFrames; p.a_batch_stride = (long)(kFrames + 2) * C;
+        p.gelu = 1; p.C = ctx->h1 + D; p.ldc = D; p.c_rows_per_batch = kFrames; p.c_batch_stride = (long)(kFrames + 2) * D;
+        launch_gemm(p, s);
+    }
+    // x = positions; x += GELU(conv2(h1)) with stride 2: A row (b,t') = h1[b][2t' .. 2t'+2][:]
+    launch_bcast_rows(ctx->enc_pos, ctx->x, B, T, D, s);
+    {
+        GemmParams p = gemm_base(ctx->h1, 2 * D, ctx->conv2_w, 3 * D, M, D, 3 * D, ctx->conv2_b);
+        p.a_rows_per_batch = T; p.a_batch_stride = (long)(kFrames + 2) * D;
+        p.gelu = 1; p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D;
+        launch_gemm(p, s);
+    }
+    for (int li = 0; li < d.enc_layers; ++li) {
+        const EncLayerW& l = ctx->enc[li];
+        launch_layernorm(ctx->x, l.ln1.g, l.ln1.b, ctx->xn, nullptr, M, D, s);
+        {
+            GemmParams p = gemm_base(ctx->xn, D, l.qkv.w, D, M, 3 * D, D, l.qkv.b);
+            p.scale = qscale; p.scale_ncols = D; p.out_mode = OUT_QKV_SPLIT;
+            p.q = ctx->q; p.k = ctx->k; p.v = ctx->vT; p.T = T; p.Tpad = ctx->Tpad; p.H = H; p.D = D;
+            launch_gemm(p, s);
+        }
+        launch_enc_attention(ctx->q, ctx->k, ctx->vT, ctx->att, B, H, T, ctx->Tpad, s);
+        {
+            GemmParams p = gemm_base(ctx->att, D, l.out.w, D, M, D, D, l.out.b);
+            p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D;
+            launch_gemm(p, s);
+        }
+        launch_layernorm(ctx->x, l.ln2.g, l.ln2.b, ctx->xn, nullptr, M, D, s);
+        {
+            GemmParams p = gemm_base(ctx->xn, D, l.fc1.w, D, M, F, D, l.fc1.b);
+            p.gelu = 1; p.C = ctx->hid; p.ldc = F;
+            launch_gemm(p, s);
+        }
+        {
+            GemmParams p = gemm_base(ctx->hid, F, l.fc2.w, F, M, D, F, l.fc2.b);
+            p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D;
+            launch_gemm(p, s);
+        }
+    }
+    launch_layernorm(ctx->x, ctx->enc_ln.g, ctx->enc_ln.b, ctx->enc_out, ctx->enc_out32, M, D, s);
+    HIPCHK(hipGetLastError());
+    return MW_OK;
+}
+
+static int run_cross_kv(mw_ctx* ctx, int B) {
+    const mw_model_desc& d = ctx->d;
+    const int D = d.d_model, H = d.n_heads, T = d.n_audio_ctx, M = B * T;
+    const size_t per_layer = (size_t)ctx->max_batch * T * D;
+    for (int li = 0; li < d.dec_layers; ++li) {
+        GemmParams p = gemm_base(ctx->enc_out, D, ctx->ckv_w + (size_t)li * 2 * D * D, D, M, 2 * D, D, ctx->ckv_b + (size_t)li * 2 * D);
+        p.out_mode = OUT_KV_SPLIT; p.k = ctx->crossK + li * per_layer; p.v = ctx->crossV + li * per_layer;
+        p.T = T; p.Tpad = T; p.H = H; p.D = D;
+        launch_gemm(p, ctx->stream);
+    }
+    HIPCHK(hipGetLastError());
+    ctx->enc_batch = B;
+    return MW_OK;
+}
+
+extern "C" int mw_encode(mw_ctx* ctx, const float* mel, int batch, float* enc_out) {
+    if (!ctx) return MW_ERR_ARG;
+    int r = check_batch(ctx, batch, "mw_encode");
+    if (r) return r;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (mel) {
+        const float* src = mel;
+        if (!is_device_ptr(mel)) {
+            HIPCHK(hipMemcpyAsync(ctx->logmel, mel, (size_t)batch * ctx->d.n_mels * kFrames * 4, hipMemcpyHostToDevice, ctx->stream));
+            src = ctx->logmel;
+        }
+        launch_mel_import(src, batch, ctx->d.n_mels, ctx->melT, ctx->stream);
+        ctx->mel_batch = batch;
+    } else if (ctx->mel_batch != batch) {
+        return fail(ctx, MW_ERR_STATE, "mw_encode: no features for this batch; call mw_logmel first or pass mel");
+    }
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    r = run_encoder(ctx, batch);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    r = run_cross_kv(ctx, batch);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    if (enc_out)
+        HIPCHK(hipMemcpyAsync(enc_out, ctx->enc_out32, (size_t)batch * ctx->d.n_audio_ctx * ctx->d.d_model * 4, hipMemcpyDefault, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventElapsedTime(&ctx->stage_ms[1], ctx->ev[1], ctx->ev[2]));
+    HIPCHK(hipEventElapsedTime(&ctx->stage_ms[2], ctx->ev[2], ctx->ev[3]));
+    return MW_OK;
+}
+
+// One greedy step: 8 launches per layer + final norm + logits + token bookkeeping.
+static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp) {
+    const mw_model_desc& d = ctx->d;
+    const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, Tc = d.n_text_ctx;
+    hipStream_t s = ctx->stream;
+    const float qscale = 1.0f / sqrtf((float)kHeadDim);
+    const size_t self_layer = (size_t)ctx->max_batch * D * Tc;
+    const size_t cross_layer = (size_t)ctx->max_batch * T * D;
+    auto base = [&](int N, int K, const LinearW& w) {
+        GemvParams p{};
+        p.B = B; p.N = N; p.K = K; p.W = w.w; p.bias = w.b; p.scale = 1.f; p.scale_ncols = 0; p.gelu = 0;
+        p.H = H; p.D = D; p.Tctx = Tc; p.st = ctx->st;
+        return p;
+    };
+    for (int li = 0; li < d.dec_layers; ++li) {
+        const DecLayerW& l = ctx->dec[li];
+        f16* sk = ctx->selfK + li * self_layer; f16* sv = ctx->selfV + li * self_layer;
+        {   // LN1 + QKV; k/v go straight into the cache at the current position
+            GemvParams p = base(3 * D, D, l.qkv);
+            p.x32 = ctx->dx; p.ln_g = l.ln1.g; p.ln_b = l.ln1.b; p.scale = qscale; p.scale_ncols = D;
+            p.out_mode = GV_QKV; p.out16 = ctx->dq; p.kcache = sk; p.vcache = sv;
+            launch_gemv(p, s);
+        }
+        launch_dec_self_attn(ctx->dq, sk, sv, ctx->datt, B, H, Tc, ctx->st, s);
+        {   GemvParams p = base(D, D, l.out); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
+        {   // LN2 + cross-attention query
+            GemvParams p = base(D, D, l.cq);
+            p.x32 = ctx->dx; p.ln_g = l.ln2.g; p.ln_b = l.ln2.b; p.scale = qscale; p.scale_ncols = D;
+            p.out_mode = GV_F16; p.out16 = ctx->dq;
+            launch_gemv(p, s);
+        }
+        launch_dec_cross_attn(ctx->dq, ctx->crossK + li * cross_layer, ctx->crossV + li * cross_layer, ctx->datt, B, H, T, s);
+        {   GemvParams p = base(D, D, l.co); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
+        {   // LN3 + fc1 + GELU
+            GemvParams p = base(F, D, l.fc1);
+            p.x32 = ctx->dx; p.ln_g = l.ln3.g; p.ln_b = l.ln3.b; p.gelu = 1; p.out_mode = GV_F16; p.out16 = ctx->dhid;
+            launch_gemv(p, s);
+        }
+        {   GemvParams p = base(D, F, l.fc2); p.xin16 = ctx->dhid; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
+    }
+    launch_layernorm(ctx->dx, ctx->dec_ln.g, ctx->dec_ln.b, ctx->dxn, nullptr, B, D, s);
+    {
+        LinearW e{ctx->tok_emb, nullptr};
+        GemvParams p = base(d.vocab, D, e);
+        p.xin16 = ctx->dxn; p.out_mode = GV_LOGITS; p.out32 = want_logits ? ctx->logits : nullptr;
+        p.mask_first = ctx->mask_first; p.mask_rest = ctx->mask_rest;
+        p.part_val = ctx->part_val; p.part_idx = ctx->part_idx; p.n_parts = ctx->n_parts;
+        launch_gemv(p, s);
+    }
+    launch_dec_finalize(fp, B, s);
+}
+
+static FinalizeParams finalize_params(mw_ctx* ctx, int n_forced) {
+    FinalizeParams fp{};
+    fp.st = ctx->st; fp.part_val = ctx->part_val; fp.part_idx = ctx->part_idx; fp.n_parts = ctx->n_parts;
+    fp.forced = ctx->forced; fp.n_forced = n_forced;
+    fp.tok_emb = ctx->tok_emb; fp.pos_emb = ctx->dec_pos; fp.D = ctx->d.d_model; fp.n_text_ctx = ctx->d.n_text_ctx; fp.vocab = ctx->d.vocab;
+    fp.x = ctx->dx; fp.out_ids = ctx->out_ids; fp.out_len = ctx->out_len; fp.finished = ctx->finished;
+    return fp;
+}
+
+// Capture (or re-use) the graph of one step for this batch size / forced length / logits flag.
+static int ensure_graph(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int key) {
+    if (ctx->graph_exec && ctx->graph_batch == key && ctx->graph_logits == (int)want_logits) return MW_OK;
+    if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+    if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_step(ctx, B, want_logits, fp);
+    HIPCHK(hipStreamEndCapture(ctx->stream, &ctx->graph));
+    HIPCHK(hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0));
+    ctx->graph_batch = key; ctx->graph_logits = (int)want_logits;
+    return MW_OK;
+}
+
+// Shared driver: feed `n_forced` given ids per sequence, then sample `max_new` more.
+static int run_decode(mw_ctx* ctx, int B, int n_forced, int max_new, float* logits_out, bool logits_every_step) {
+    const mw_model_desc& d = ctx->d;
+    hipStream_t s = ctx->stream;
+    FinalizeParams fp = finalize_params(ctx, n_forced);
+    launch_dec_init(fp, B, n_forced, max_new, ctx->eot, s);
+    HIPCHK(hipGetLastError());
+    const bool want_logits = logits_out != nullptr;
+    const int n_steps = max_new > 0 ? n_forced + max_new - 1 : n_forced;
+    const bool graph = ctx->use_graph != 0;
+    if (graph) {
+        int r = ensure_graph(ctx, B, want_logits, fp, B * 1024 + n_forced);
+        if (r) return r;
+    }
+    const size_t row = (size_t)B * d.vocab;
+    int host_fin = 0;
+    int steps_run = 0;
+    for (int step = 0; step < n_steps; ++step) {
+        if (graph) HIPCHK(hipGraphLaunch(ctx->graph_exec, s));
+        else { enqueue_step(ctx, B, want_logits, fp); HIPCHK(hipGetLastError()); }
+        ++steps_run;
+        if (want_logits) {
+            // step feeds position `step`; its logits choose the token for position step + 1
+            if (logits_every_step) {
+                HIPCHK(hipMemcpyAsync(logits_out + (size_t)step * row, ctx->logits, row * 4, hipMemcpyDefault, s));
+            } else if (step >= n_forced - 1) {
+                HIPCHK(hipMemcpyAsync(logits_out + (size_t)(step - (n_forced - 1)) * row, ctx->logits, row * 4, hipMemcpyDefault, s));
+            }
+        }
+        if (max_new > 0 && step >= n_forced - 1 && ((step - (n_forced - 1)) % ctx->check_every) == ctx->check_every - 1 && step + 1 < n_steps) {
+            HIPCHK(hipMemcpyAsync(&host_fin, &ctx->st->n_finished, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (host_fin >= B) break;
+        }
+    }
+    ctx->stage_ms[4] = (float)steps_run;
+    return MW_OK;
+}
+
+extern "C" int mw_decode_greedy(mw_ctx* ctx, int batch, int32_t* out_ids, int32_t* out_len, float* logits_out) {
+    if (!ctx) return MW_ERR_ARG;
+    int r = check_batch(ctx, batch, "mw_decode_greedy");
+    if (r) return r;
+    if (!ctx->opts_set) return fail(ctx, MW_ERR_STATE, "mw_decode_greedy: call mw_set_decode_opts first");
+    if (ctx->enc_batch != batch) return fail(ctx, MW_ERR_STATE, "mw_decode_greedy: batch differs from the last mw_encode");
+    if (!out_ids || !out_len) return fail(ctx, MW_ERR_ARG, "mw_decode_greedy: null output");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int P = (int)ctx->prompt.size();
+    std::vector<int32_t> f((size_t)batch * P);
+    for (int b = 0; b < batch; ++b) memcpy(&f[(size_t)b * P], ctx->prompt.data(), P * 4);
+    HIPCHK(hipMemcpyAsync(ctx->forced, f.data(), f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    r = run_decode(ctx, batch, P, ctx->max_new, logits_out, false);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_ids, ctx->out_ids, (size_t)batch * ctx->max_new * 4, hipMemcpyDefault, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_len, ctx->out_len, (size_t)batch * 4, hipMemcpyDefault, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventElapsedTime(&ctx->stage_ms[3], ctx->ev[3], ctx->ev[4]));
+    return MW_OK;
+}
+
+extern "C" int mw_decode_forced(mw_ctx* ctx, int batch, const int32_t* tokens, int n, float* logits_out) {
+    if (!ctx) return MW_ERR_ARG;
+    int r = check_batch(ctx, batch, "mw_decode_forced");
+    if (r) return r;
+    if (ctx->enc_batch != batch) return fail(ctx, MW_ERR_STATE, "mw_decode_forced: batch differs from the last mw_encode");
+    if (!tokens || !logits_out || n < 1 || n > ctx->d.n_text_ctx) return fail(ctx, MW_ERR_ARG, "mw_decode_forced: bad tokens / n / output");
+    for (long i = 0; i < (long)batch * n; ++i)
+        if (tokens[i] < 0 || tokens[i] >= ctx->d.vocab) return fail(ctx, MW_ERR_ARG, "mw_decode_forced: token id out of range");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(ctx->forced, tokens, (size_t)batch * n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // logits come back step-major [n][batch][vocab]; transposed to [batch][n][vocab] below
+    const size_t V = ctx->d.vocab;
+    std::vector<float> tmp((size_t)n * batch * V);
+    r = run_decode(ctx, batch, n, 0, tmp.data(), true);
+    if (r) return r;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < n; ++j)
+        for (int b = 0; b < batch; ++b)
+            memcpy(logits_out + ((size_t)b * n + j) * V, &tmp[((size_t)j * batch + b) * V], V * 4);
+    return MW_OK;
+}
+
+extern "C" int mw_transcribe_batch(mw_ctx* ctx, const float* pcm, int batch, int32_t* out_ids, int32_t* out_len) {
+    if (!ctx) return MW_ERR_ARG;
+    int r = check_batch(ctx, batch, "mw_transcribe_batch");
+    if (r) return r;
+    if (!ctx->opts_set) return fail(ctx, MW_ERR_STATE, "mw_transcribe_batch: call mw_set_decode_opts first");
+    if (!pcm || !out_ids || !out_len) return fail(ctx, MW_ERR_ARG, "mw_transcribe_batch: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const float* src = pcm;
+    if (!is_device_ptr(pcm)) {
+        HIPCHK(hipMemcpyAsync(ctx->pcm_dev, pcm, (size_t)batch * kChunkSamples * 4, hipMemcpyHostToDevice, s));
+        src = ctx->pcm_dev;
+    }
+    const int P = (int)ctx->prompt.size();
+    std::vector<int32_t> f((size_t)batch * P);
+    for (int b = 0; b < batch; ++b) memcpy(&f[(size_t)b * P], ctx->prompt.data(), P * 4);
+    HIPCHK(hipMemcpyAsync(ctx->forced, f.data(), f.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));       // `f` is pageable host memory that dies with this scope
+    HIPCHK(hipEventRecord(ctx->ev[0], s));
+    r = run_logmel(ctx, src, batch);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[1], s));
+    r = run_encoder(ctx, batch);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[2], s));
+    r = run_cross_kv(ctx, batch);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[3], s));
+    r = run_decode(ctx, batch, P, ctx->max_new, nullptr, false);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[4], s));
+    HIPCHK(hipMemcpyAsync(out_ids, ctx->out_ids, (size_t)batch * ctx->max_new * 4, hipMemcpyDefault, s));
+    HIPCHK(hipMemcpyAsync(out_len, ctx->out_len, (size_t)batch * 4, hipMemcpyDefault, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < 4; ++i) HIPCHK(hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+    return MW_OK;
+}
+
+extern "C" int mw_stage_ms(mw_ctx* ctx, float out[5]) {
+    if (!ctx || !out) return MW_ERR_ARG;
+    for (int i = 0; i < 5; ++i) out[i] = ctx->stage_ms[i];
+    return MW_OK;
+}
+
+extern "C" int mw_profile_cross_attention(mw_ctx* ctx, int batch, int iters, float* mean_ms, double* bytes_per_launch) {
+    if (!ctx) return MW_ERR_ARG;
+    int r = check_batch(ctx, batch, "mw_profile_cross_attention");
+    if (r) return r;
+    if (iters < 1 || !mean_ms || !bytes_per_launch) return fail(ctx, MW_ERR_ARG, "mw_profile_cross_attention: bad argument");
+    if (ctx->enc_batch != batch) return fail(ctx, MW_ERR_STATE, "mw_profile_cross_attention: encode this batch first");
+    HIPCHK(hipSetDevice(ctx->device));
+    const mw_model_desc& d = ctx->d;
+    const size_t cross_layer = (size_t)ctx->max_batch * d.n_audio_ctx * d.d_model;
+    // cycle over the layers so that successive launches read different cache regions, as in a real step
+    launch_dec_cross_attn(ctx->dq, ctx->crossK, ctx->crossV, ctx->datt, batch, d.n_heads, d.n_audio_ctx, ctx->stream);
+    HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
+    for (int i = 0; i < iters; ++i) {
+        const int li = i % d.dec_layers;
+        launch_dec_cross_attn(ctx->dq, ctx->crossK + li * cross_layer, ctx->crossV + li * cross_layer, ctx->datt, batch,
+                              d.n_heads, d.n_audio_ctx, ctx->stream);
+    }
+    HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[4]));
+    *mean_ms = ms / iters;
+    *bytes_per_launch = 2.0 * batch * d.n_audio_ctx * (double)d.d_model * 2.0;    // K and V, fp16
+    return MW_OK;
+}

@@ -1,0 +1,274 @@
+// Encoder-side kernels other than the GEMM: LayerNorm, position-table broadcast, the
+// non-causal flash attention over 1500 frames, and the weight import conversions.
+#include "mw_kernels.h"
+
+namespace mw {
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------ LayerNorm
+// One wave per row (fp32 in, fp32 statistics, eps 1e-5), 4 rows per workgroup; the row stays in
+// registers between the two passes so HBM sees one read and one fp16 write.
+// modeling_whisper.py:392,402,642 (nn.LayerNorm defaults).
+constexpr int LN_MAXV = 8;     // D <= 2048
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, f16* __restrict__ y,
+                                                        float* __restrict__ y32, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * D;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            v[i] = *reinterpret_cast<const float4*>(xr + c);
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + c);
+            const float4 bb = *reinterpret_cast<const float4*>(b + c);
+            const float o0 = v[i].x * rstd * gg.x + bb.x, o1 = v[i].y * rstd * gg.y + bb.y;
+            const float o2 = v[i].z * rstd * gg.z + bb.z, o3 = v[i].w * rstd * gg.w + bb.w;
+            if (y) *reinterpret_cast<half4*>(y + (long)row * D + c) = half4{(f16)o0, (f16)o1, (f16)o2, (f16)o3};
+            if (y32) *reinterpret_cast<float4*>(y32 + (long)row * D + c) = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+
+__global__ void bcast_rows_kernel(const float* __restrict__ table, float* __restrict__ x, long per_batch, long total) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i < total) *reinterpret_cast<float4*>(x + i) = *reinterpret_cast<const float4*>(table + (i % per_batch));
+}
+
+// ------------------------------------------------------------------ encoder attention
+// softmax(Q K^T) V per (batch, head), non-causal, no mask (modeling_whisper.py:228-235 with
+// scaling already applied to q, :309).  Workgroup = 128 queries (4 waves x 32), KV tiles of 64.
+//
+// S^T = K Q^T is computed with keys on the MFMA row index, so a lane holds, for ONE query
+// (column lane&15), 4 keys per 16-key tile: the running max / sum of the online softmax need only
+// the 4 lanes that share a column (two xor shuffles).  Those same registers, converted to fp16,
+// are directly the B operand of O^T = V^T P^T (k index = key) once V^T fragments are fetched
+// with the matching key permutation; V arrives already transposed ([64][T]) from the QKV GEMM, so
+// each fragment is two 8-byte LDS reads.  Output O^T has the query on the lane again, so the
+// rescale factors are per-lane scalars.
+constexpr int AQ = 128, AKV = 64;
+
+__device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+__global__ __launch_bounds__(256) void enc_attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                            const f16* __restrict__ vT, f16* __restrict__ out, int H,
+                                                            int T, int Tpad) {
+    __shared__ __attribute__((aligned(16))) f16 lds[2][2][AKV * 64];     // [buffer][K | V^T][64 x 64] = 32 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int bh = blockIdx.y;
+    const int q0 = blockIdx.x * AQ + wave * 32;
+    const f16* qb = q + (long)bh * T * 64;
+    const f16* kb = k + (long)bh * T * 64;
+    const f16* vb = vT + (long)bh * 64 * Tpad;
+
+    // Q fragments (B operand: column = query, k = head-dim), straight from global.
+    half8 qf[2][2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        int row = q0 + qs * 16 + fr;
+        if (row >= T) row = T - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[qs][ks] = *reinterpret_cast<const half8*>(qb + (long)row * 64 + ks * 32 + fg * 8);
+    }
+
+    // staging: each thread moves two 16-byte chunks of K and two of V^T per tile
+    uint4 rk[2], rv[2];
+    const int ch = tid & 7;
+    auto gload = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            const int key = kv0 + row;
+            rk[i] = key < T ? *reinterpret_cast<const uint4*>(kb + (long)key * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+            const int kc = kv0 + ch * 8;             // V^T: row = head-dim index, chunk = 8 keys
+            rv[i] = kc < Tpad ? *reinterpret_cast<const uint4*>(vb + (long)row * Tpad + kc) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<uint4*>(&lds[buf][0][swz64(row, ch)]) = rk[i];
+            *reinterpret_cast<uint4*>(&lds[buf][1][swz64(row, ch)]) = rv[i];
+        }
+    };
+
+    float4v o[4][2];           // [head-dim tile][query tile]: O^T
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i][0] = float4v{0, 0, 0, 0}; o[i][1] = float4v{0, 0, 0, 0}; }
+    float mrun[2] = {-1.0e30f, -1.0e30f}, lrun[2] = {0.f, 0.f};
+
+    const int ntile = (T + AKV - 1) / AKV;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const int buf = it & 1, kv0 = it * AKV;
+        if (it + 1 < ntile) gload(kv0 + AKV);
+
+        // ---- S^T tiles: [key tile i][query tile qs]
+        float4v sc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc[i][0] = float4v{0, 0, 0, 0}; sc[i][1] = float4v{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const half8 kf = *reinterpret_cast<const half8*>(&lds[buf][0][swz64(i * 16 + fr, ks * 4 + fg)]);
+                sc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], sc[i][0], 0, 0, 0);
+                sc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], sc[i][1], 0, 0, 0);
+            }
+        }
+        if (kv0 + AKV > T) {      // last tile: keys past the end contribute nothing
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kv0 + i * 16 + 4 * fg + r >= T) { sc[i][0][r] = -1.0e30f; sc[i][1][r] = -1.0e30f; }
+        }
+        // ---- online softmax per query column
+        half8 pf[2][2];            // [query tile][k step of 32 keys]
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            float mx = sc[0][qs][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[i][qs][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[qs], mx);
+            const float alpha = __expf(mrun[qs] - mnew);
+            mrun[qs] = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __expf(sc[i][qs][r] - mnew);
+                    sc[i][qs][r] = pv;
+                    ps += pv;
+                }
+            lrun[qs] = lrun[qs] * alpha + ps;           // partial over this lane's keys; reduced at the end
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[i][qs][0] *= alpha; o[i][qs][1] *= alpha; o[i][qs][2] *= alpha; o[i][qs][3] *= alpha; }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                pf[qs][s] = half8{(f16)sc[2 * s][qs][0], (f16)sc[2 * s][qs][1], (f16)sc[2 * s][qs][2], (f16)sc[2 * s][qs][3],
+                                  (f16)sc[2 * s + 1][qs][0], (f16)sc[2 * s + 1][qs][1], (f16)sc[2 * s + 1][qs][2],
+                                  (f16)sc[2 * s + 1][qs][3]};
+        }
+        // ---- O^T += V^T P^T ; element j of k-step s is key 32s + 16(j>>2) + 4*fg + (j&3)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int row = dt * 16 + fr;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // keys 32s+4fg..+3 sit in chunk 4s + (fg>>1) at half offset 4*(fg&1); +16 keys = chunk + 2
+                const int c0 = 4 * s + (fg >> 1), off = 4 * (fg & 1);
+                const half4 lo = *reinterpret_cast<const half4*>(&lds[buf][1][swz64(row, c0) + off]);
+                const half4 hi = *reinterpret_cast<const half4*>(&lds[buf][1][swz64(row, c0 + 2) + off]);
+                const half8 vf = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0][s], o[dt][0], 0, 0, 0);
+                o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][s], o[dt][1], 0, 0, 0);
+            }
+        }
+        if (it + 1 < ntile) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds O[query][16dt + 4fg .. +3]
+    const int b = bh / H, h = bh - b * H;
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        float l = lrun[qs];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int row = q0 + qs * 16 + fr;
+        if (row < T) {
+            f16* dst = out + ((long)b * T + row) * (H * 64) + h * 64 + 4 * fg;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<half4*>(dst + dt * 16) =
+                    half4{(f16)(o[dt][qs][0] * inv), (f16)(o[dt][qs][1] * inv), (f16)(o[dt][qs][2] * inv), (f16)(o[dt][qs][3] * inv)};
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight import
+__device__ __forceinline__ float load_as_f32(const void* src, int dt, long i) {
+    if (dt == 0) return reinterpret_cast<const float*>(src)[i];
+    if (dt == 1) return (float)reinterpret_cast<const f16*>(src)[i];
+    const unsigned int u = (unsigned int)reinterpret_cast<const unsigned short*>(src)[i] << 16;   // bf16
+    return __uint_as_float(u);
+}
+
+__global__ void convert_kernel(const void* __restrict__ src, int dt, void* __restrict__ dst, int to_f16, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = load_as_f32(src, dt, i);
+    if (to_f16) reinterpret_cast<f16*>(dst)[i] = (f16)v; else reinterpret_cast<float*>(dst)[i] = v;
+}
+
+__global__ void conv_permute_kernel(const void* __restrict__ src, int dt, f16* __restrict__ dst, int D, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // index into dst [D][3][C]
+    if (i >= (long)D * 3 * C) return;
+    const int c = i % C, j = (i / C) % 3, d = i / (3L * C);
+    dst[i] = (f16)load_as_f32(src, dt, ((long)d * C + c) * 3 + j);
+}
+
+}  // namespace
+
+void launch_layernorm(const float* x, const float* g, const float* b, f16* y, float* y32, int rows, int D, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, y32, rows, D);
+}
+
+void launch_bcast_rows(const float* table, float* x, int B, int rows, int D, hipStream_t s) {
+    const long per = (long)rows * D, total = per * B;
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, table, x, per, total);
+}
+
+void launch_enc_attention(const f16* q, const f16* k, const f16* vT, f16* out, int B, int H, int T, int Tpad, hipStream_t s) {
+    hipLaunchKernelGGL(enc_attention_kernel, dim3((T + AQ - 1) / AQ, B * H), dim3(256), 0, s, q, k, vT, out, H, T, Tpad);
+}
+
+void launch_convert(const void* src, int src_dtype, void* dst, int dst_is_f16, long n, hipStream_t s) {
+    hipLaunchKernelGGL(convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, src_dtype, dst, dst_is_f16, n);
+}
+
+void launch_conv_permute(const void* src, int src_dtype, f16* dst, int D, int C, hipStream_t s) {
+    const long n = (long)D * 3 * C;
+    hipLaunchKernelGGL(conv_permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, src_dtype, dst, D, C);
+}
+
+}  // namespace mw

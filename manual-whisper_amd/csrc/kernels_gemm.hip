@@ -1,0 +1,166 @@
+// fp16 x fp16 -> fp32 MFMA GEMM with fused epilogues, for the encoder and the cross-attention
+// K/V projection (M = batch*1500 rows, K and N in the thousands: MFMA-bound).
+//
+//   C[m][n] = epi( sum_k A[m][k] * W[n][k] )      A: activations, W: nn.Linear weight [out][in]
+//
+// Tile 128x128x64, 256 threads = 4 waves in a 2x2 grid, each wave 64x64 as 4x4 tiles of
+// v_mfma_f32_16x16x32_f16.  Both operands are K-contiguous, so every fragment is one
+// ds_read_b128 from an XOR-swizzled LDS image (16-byte chunk index ^ ((row>>1)&7): the 16 rows a
+// ds_read_b128 lane group touches land on 16 distinct slots of the 256-byte bank row).
+// Global->LDS staging goes through registers and is issued one K-tile ahead of the MFMAs.
+// The weight fragment is the MFMA's A operand and the activation fragment its B operand, so each
+// lane ends up with 4 consecutive output columns of one row: bias loads and stores are vector.
+//
+// A and C rows may be "batched with gaps": row m lives at (m / rows_per_batch) * batch_stride +
+// (m % rows_per_batch) * ld.  With ld smaller than K consecutive rows overlap, which is how the
+// k=3 convolutions of the encoder stem run as plain GEMMs over a time-major padded buffer.
+#include "mw_kernels.h"
+
+namespace mw {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+__device__ __forceinline__ int swz(int row, int chunk) {      // offset in halfs inside a [rows][64] tile
+    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) f16 lds[2][2][BM * BK];   // [buffer][A|W][tile] = 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
+    // contiguous run of tiles so neighbours that share an A row-panel hit the same L2.
+    const int nt_n = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / nt_n) * BM, n0 = (bid % nt_n) * BN;
+
+    // staging: 4 chunks of 16 B per thread per operand; chunk id = tid + 256*i -> row = id>>3, col chunk = id&7
+    const f16* a_ptr[4];
+    const f16* w_ptr[4];
+    bool a_ok[4], w_ok[4];
+    const int ch = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int m = m0 + row, n = n0 + row;
+        a_ok[i] = m < p.M;
+        w_ok[i] = n < p.N;
+        const int mm = a_ok[i] ? m : 0, nn = w_ok[i] ? n : 0;
+        a_ptr[i] = p.A + (long)(mm / p.a_rows_per_batch) * p.a_batch_stride + (long)(mm % p.a_rows_per_batch) * p.lda + ch * 8;
+        w_ptr[i] = p.W + (long)nn * p.ldw + ch * 8;
+    }
+    uint4 ra[4], rw[4];
+    auto gload = [&](int k0) {
+        const bool k_ok = (k0 + ch * 8) < p.K;      // K is a multiple of 8: a chunk is all in or all out
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = (a_ok[i] && k_ok) ? *reinterpret_cast<const uint4*>(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+            rw[i] = (w_ok[i] && k_ok) ? *reinterpret_cast<const uint4*>(w_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<uint4*>(&lds[buf][0][swz(row, ch)]) = ra[i];
+            *reinterpret_cast<uint4*>(&lds[buf][1][swz(row, ch)]) = rw[i];
+        }
+    };
+
+    float4v acc[4][4];   // [n subtile][m subtile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 wf[4], af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wf[i] = *reinterpret_cast<const half8*>(&lds[buf][1][swz(wn * 64 + i * 16 + fr, ks * 4 + fg)]);
+                af[i] = *reinterpret_cast<const half8*>(&lds[buf][0][swz(wm * 64 + i * 16 + fr, ks * 4 + fg)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*64 + j*16 + fr, n = n0 + wn*64 + i*16 + 4*fg
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + fr;
+        if (m >= p.M) continue;
+        int bb = 0, tt = 0;
+        if (p.out_mode >= OUT_QKV_SPLIT) { bb = m / p.T; tt = m - bb * p.T; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + 4 * fg;
+            if (n >= p.N) continue;                     // N is a multiple of 4
+            float4v v = acc[i][j];
+            if (p.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            if (n < p.scale_ncols) { v[0] *= p.scale; v[1] *= p.scale; v[2] *= p.scale; v[3] *= p.scale; }
+            if (p.gelu) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+            if (p.out_mode == OUT_RESID_F32) {
+                float* c = reinterpret_cast<float*>(p.C) + (long)(m / p.c_rows_per_batch) * p.c_batch_stride +
+                           (long)(m % p.c_rows_per_batch) * p.ldc + n;
+                float4 o = *reinterpret_cast<float4*>(c);
+                o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+                *reinterpret_cast<float4*>(c) = o;
+            } else {
+                half4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                if (p.out_mode == OUT_F16) {
+                    f16* c = reinterpret_cast<f16*>(p.C) + (long)(m / p.c_rows_per_batch) * p.c_batch_stride +
+                             (long)(m % p.c_rows_per_batch) * p.ldc + n;
+                    *reinterpret_cast<half4*>(c) = h;
+                } else {
+                    const int sec = n / p.D, nn = n - sec * p.D;
+                    const int hh = nn >> 6, e = nn & 63;
+                    const long bh = (long)bb * p.H + hh;
+                    if (p.out_mode == OUT_QKV_SPLIT && sec == 2) {           // V transposed: [B][H][64][Tpad]
+                        f16* c = p.v + (bh * 64 + e) * p.Tpad + tt;
+                        c[0] = h[0]; c[p.Tpad] = h[1]; c[2L * p.Tpad] = h[2]; c[3L * p.Tpad] = h[3];
+                    } else {
+                        f16* base = (p.out_mode == OUT_QKV_SPLIT) ? (sec == 0 ? p.q : p.k) : (sec == 0 ? p.k : p.v);
+                        *reinterpret_cast<half4*>(base + (bh * p.T + tt) * 64 + e) = h;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+void launch_gemm(const GemmParams& p, hipStream_t s) {
+    const int nt = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_kernel, dim3(nt), dim3(256), 0, s, p);
+}
+
+}  // namespace mw

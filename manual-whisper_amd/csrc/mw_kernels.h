@@ -1,0 +1,114 @@
+// Internal launch interface between the engine and its gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace mw {
+
+typedef _Float16 f16;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int kChunkSamples = 480000;
+constexpr int kFrames = 3000;
+constexpr int kNfft = 400;
+constexpr int kHop = 160;
+constexpr int kFreqPad = 256;   // 201 DFT bins padded to 8 tiles of 32
+constexpr int kHeadDim = 64;
+
+// ---------------------------------------------------------------- log-mel
+struct MelTables {
+    const float* basis_cos;   // [400][256]  hann[n]*cos(2*pi*f*n/400), zero for f >= 201
+    const float* basis_sin;   // [400][256] -hann[n]*sin(...)
+    const float* filt;        // [256][n_mels_pad] mel filter bank, zero padded
+    int n_mels, n_mels_pad;
+};
+// pcm [B][480000] -> raw log10 mel [B][n_mels][3000] + per-block maxima [B][94]
+void launch_mel_dft(const float* pcm, int B, const MelTables& t, float* logmel, float* blockmax, hipStream_t s);
+// clamp/scale in place, and write the time-major fp16 copy melT [B][3002][n_mels] (rows 0 and 3001 stay zero)
+void launch_mel_norm(float* logmel, const float* blockmax, int B, int n_mels, f16* melT, hipStream_t s);
+// float32 features supplied by the caller -> melT
+void launch_mel_import(const float* mel, int B, int n_mels, f16* melT, hipStream_t s);
+
+// ---------------------------------------------------------------- big GEMM (encoder, cross K/V)
+enum GemmOut { OUT_F16 = 0, OUT_RESID_F32 = 1, OUT_QKV_SPLIT = 2, OUT_KV_SPLIT = 3 };
+struct GemmParams {
+    // C[m][n] = epilogue( sum_k A[m][k] * W[n][k] ), fp16 operands, fp32 accumulate
+    const f16* A; long lda; int a_rows_per_batch; long a_batch_stride;
+    const f16* W; long ldw;
+    int M, N, K;
+    const float* bias;        // [N] or null
+    float scale; int scale_ncols;   // columns n < scale_ncols are multiplied by scale after the bias
+    int gelu;
+    int out_mode;
+    void* C; long ldc; int c_rows_per_batch; long c_batch_stride;   // OUT_F16 / OUT_RESID_F32
+    f16* q; f16* k; f16* v;   // split modes: q,k [B][H][T][64]; v is [B][H][64][Tpad] (QKV) or [B][H][T][64] (KV)
+    int T, Tpad, H, D;
+};
+void launch_gemm(const GemmParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------- encoder helpers
+void launch_layernorm(const float* x, const float* g, const float* b, f16* y, float* y32, int rows, int D, hipStream_t s);
+void launch_bcast_rows(const float* table, float* x, int B, int rows, int D, hipStream_t s);   // x[b][r][:] = table[r][:]
+// q,k [B][H][T][64], vT [B][H][64][Tpad] -> out [B*T][H*64] fp16
+void launch_enc_attention(const f16* q, const f16* k, const f16* vT, f16* out, int B, int H, int T, int Tpad, hipStream_t s);
+
+// ---------------------------------------------------------------- weight import
+void launch_convert(const void* src, int src_dtype, void* dst, int dst_is_f16, long n, hipStream_t s);
+// conv weight [D][C][3] (any dtype) -> fp16 [D][3][C]
+void launch_conv_permute(const void* src, int src_dtype, f16* dst, int D, int C, hipStream_t s);
+
+// ---------------------------------------------------------------- decode step
+struct DecState {          // lives in device memory; one per context
+    int pos;               // position of the token whose embedding is in x
+    int prompt_len;
+    int max_new;
+    int eot;
+    int n_finished;
+    int batch;
+    int pad[2];
+};
+enum GemvOut { GV_F16 = 0, GV_RESID = 1, GV_QKV = 2, GV_LOGITS = 3 };
+struct GemvParams {
+    int B, N, K;
+    const f16* W;             // [N][K]
+    const float* bias;        // [N] or null
+    // input: LayerNorm(x32; ln_g, ln_b) when ln_g != null, else xin16
+    const float* x32; const float* ln_g; const float* ln_b;
+    const f16* xin16;
+    float scale; int scale_ncols; int gelu;
+    int out_mode;
+    f16* out16;               // GV_F16: [B][N];  GV_QKV: q [B][D]
+    float* out32;             // GV_RESID: x [B][N] += ;  GV_LOGITS: logits [B][N]
+    f16* kcache; f16* vcache; // GV_QKV: [B][H][Tctx][64] of this layer
+    int H, D, Tctx;
+    const DecState* st;
+    // GV_LOGITS
+    const uint8_t* mask_first; const uint8_t* mask_rest;
+    float* part_val; int* part_idx; int n_parts;   // [B][n_parts]
+};
+void launch_gemv(const GemvParams& p, hipStream_t s);
+int gemv_logits_parts(int N);
+
+void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx,
+                          const DecState* st, hipStream_t s);
+void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, hipStream_t s);
+
+struct FinalizeParams {
+    DecState* st;
+    const float* part_val; const int* part_idx; int n_parts;
+    const int* forced;          // [B][n_forced] ids fed before sampling starts (prompt, or teacher-forced ids)
+    int n_forced;
+    const f16* tok_emb; const f16* pos_emb; int D; int n_text_ctx; int vocab;
+    float* x;                   // [B][D]
+    int* out_ids;               // [B][max_new]
+    int* out_len;               // [B]
+    int* finished;              // [B]
+};
+void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s);
+void launch_dec_finalize(const FinalizeParams& p, int B, hipStream_t s);
+
+}  // namespace mw

@@ -1,0 +1,162 @@
+"""Python face of the HIP engine: thin, typed wrappers over the C ABI.
+
+PyTorch appears only as a container for weights (``tensor.data_ptr()``); all
+compute happens inside libmwhip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .decode_options import DecodeOptions
+from .dims import CHUNK_SAMPLES, N_FRAMES, WhisperDims
+
+_DTYPES = {"float32": 0, "float16": 1, "bfloat16": 2}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _ptr(a) -> C.c_void_p:
+    """Address of a numpy array or a torch tensor (host or device)."""
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(a.data_ptr())
+
+
+class Engine:
+    """One GPU's engine.  ``max_batch`` chunks of 30 s are processed per call."""
+
+    def __init__(self, dims: WhisperDims, device: int = 0, max_batch: int = 16):
+        self._lib = _lib.load()
+        self.dims = dims
+        self.device = device
+        self.max_batch = max_batch
+        self.opts: Optional[DecodeOptions] = None
+        desc = _lib.ModelDesc(dims.n_mels, dims.d_model, dims.n_heads, dims.enc_layers, dims.dec_layers,
+                              dims.ffn_dim, dims.vocab, dims.n_audio_ctx, dims.n_text_ctx)
+        h = C.c_void_p()
+        rc = self._lib.mw_create(C.byref(desc), device, max_batch, C.byref(h))
+        if rc != 0:
+            raise EngineError(f"mw_create failed ({rc}): {self._lib.mw_last_error(None).decode()}")
+        self._h = h
+
+    # -- plumbing -------------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise EngineError(f"{what} failed ({rc}): {self._lib.mw_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mw_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key: str, value: int):
+        self._check(self._lib.mw_set_option(self._h, key.encode(), int(value)), "mw_set_option")
+
+    # -- weights ----------------------------------------------------------------
+    def load_weights(self, weights: Mapping[str, object]):
+        """``weights``: HF-layout state dict of numpy arrays or torch tensors (CPU or this GPU)."""
+        for name, w in weights.items():
+            if isinstance(w, np.ndarray):
+                w = np.ascontiguousarray(w)
+                dt = _DTYPES.get(str(w.dtype))
+                shape = w.shape
+            else:
+                w = w.contiguous()
+                dt = _DTYPES.get(str(w.dtype).replace("torch.", ""))
+                shape = tuple(w.shape)
+            if dt is None:
+                raise EngineError(f"weight {name}: unsupported dtype {w.dtype}")
+            shp = (C.c_int64 * len(shape))(*shape)
+            self._check(self._lib.mw_set_weight(self._h, name.encode(), _ptr(w), shp, len(shape), dt),
+                        f"mw_set_weight({name})")
+        self._check(self._lib.mw_finalize(self._h), "mw_finalize")
+
+    def set_decode_options(self, o: DecodeOptions):
+        prompt = (C.c_int32 * len(o.prompt))(*o.prompt)
+        sup_l = o.effective_suppress()
+        sup = (C.c_int32 * max(1, len(sup_l)))(*sup_l)
+        # a suppressed EOT must not be re-enabled by the begin list; it is a union anyway
+        bsup = (C.c_int32 * max(1, len(o.begin_suppress)))(*o.begin_suppress)
+        s = _lib.DecodeOpts(prompt, len(o.prompt), sup, len(sup_l), bsup, len(o.begin_suppress), o.eot, o.max_new)
+        self._check(self._lib.mw_set_decode_opts(self._h, C.byref(s)), "mw_set_decode_opts")
+        self.opts = o
+
+    # -- stages -------------------------------------------------------------------
+    @staticmethod
+    def _pcm_batch(pcm) -> int:
+        shape = tuple(pcm.shape)
+        if len(shape) != 2 or shape[1] != CHUNK_SAMPLES:
+            raise EngineError(f"pcm must be [batch, {CHUNK_SAMPLES}] float32, got {shape}")
+        if "float32" not in str(pcm.dtype):
+            raise EngineError(f"pcm must be float32, got {pcm.dtype}")
+        return shape[0]
+
+    def logmel(self, pcm, want_output: bool = True) -> Optional[np.ndarray]:
+        B = self._pcm_batch(pcm)
+        out = np.empty((B, self.dims.n_mels, N_FRAMES), np.float32) if want_output else None
+        self._check(self._lib.mw_logmel(self._h, _ptr(pcm), B, _ptr(out) if want_output else None), "mw_logmel")
+        return out
+
+    def encode(self, batch: int, mel: Optional[np.ndarray] = None, want_output: bool = True) -> Optional[np.ndarray]:
+        if mel is not None:
+            mel = np.ascontiguousarray(mel, dtype=np.float32)
+            if mel.shape != (batch, self.dims.n_mels, N_FRAMES):
+                raise EngineError(f"mel must be {(batch, self.dims.n_mels, N_FRAMES)}, got {mel.shape}")
+        out = np.empty((batch, self.dims.n_audio_ctx, self.dims.d_model), np.float32) if want_output else None
+        self._check(self._lib.mw_encode(self._h, _ptr(mel) if mel is not None else None, batch,
+                                        _ptr(out) if want_output else None), "mw_encode")
+        return out
+
+    def decode_greedy(self, batch: int, want_logits: bool = False):
+        if self.opts is None:
+            raise EngineError("set_decode_options first")
+        ids = np.empty((batch, self.opts.max_new), np.int32)
+        lens = np.empty(batch, np.int32)
+        logits = np.zeros((self.opts.max_new, batch, self.dims.vocab), np.float32) if want_logits else None
+        self._check(self._lib.mw_decode_greedy(self._h, batch, _ptr(ids), _ptr(lens),
+                                               _ptr(logits) if want_logits else None), "mw_decode_greedy")
+        return ids, lens, logits
+
+    def decode_forced(self, tokens: np.ndarray) -> np.ndarray:
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        B, n = tokens.shape
+        out = np.empty((B, n, self.dims.vocab), np.float32)
+        self._check(self._lib.mw_decode_forced(self._h, B, _ptr(tokens), n, _ptr(out)), "mw_decode_forced")
+        return out
+
+    def transcribe_batch(self, pcm):
+        """pcm: numpy [B, 480000] float32 on the host, or a torch tensor already on this GPU."""
+        if self.opts is None:
+            raise EngineError("set_decode_options first")
+        B = self._pcm_batch(pcm)
+        ids = np.empty((B, self.opts.max_new), np.int32)
+        lens = np.empty(B, np.int32)
+        self._check(self._lib.mw_transcribe_batch(self._h, _ptr(pcm), B, _ptr(ids), _ptr(lens)), "mw_transcribe_batch")
+        return ids, lens
+
+    # -- measurement --------------------------------------------------------------------
+    def stage_ms(self) -> dict:
+        a = (C.c_float * 5)()
+        self._check(self._lib.mw_stage_ms(self._h, a), "mw_stage_ms")
+        return {"logmel": a[0], "encoder": a[1], "cross_kv": a[2], "decode": a[3], "decode_steps": int(a[4])}
+
+    def profile_cross_attention(self, batch: int, iters: int = 64):
+        ms, nbytes = C.c_float(), C.c_double()
+        self._check(self._lib.mw_profile_cross_attention(self._h, batch, iters, C.byref(ms), C.byref(nbytes)),
+                    "mw_profile_cross_attention")
+        return ms.value, nbytes.value
+
+    def synchronize(self):
+        self._check(self._lib.mw_synchronize(self._h), "mw_synchronize")

@@ -1,0 +1,317 @@
+"""CPU oracle for the Whisper transcription hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is the checker, never the product: only tests/, the smoke() entry and
+the cpu_baseline leg of bench.py may import it.  The shipped path is the HIP
+library and raises when that library is missing.
+
+What it restates.  The reference (transcribe.py:107-123) delegates the whole
+numeric path to whisperx 3.7.6 (pinned only in transcribe_colab.ipynb:47,80;
+unpinned in requirements.txt:1), which runs faster-whisper / CTranslate2.  None
+of those packages, nor any pretrained weight, exists offline, and the reference
+holds no test or golden vector for this path: PARITY WITH THE REFERENCE ITSELF
+IS UNPINNED.  The algorithm restated here is the published Whisper forward
+pass, following the Hugging Face implementation line by line where cited, and
+it is pinned against that implementation (transformers 5.15.0, fp32, seeded
+synthetic weights) by the fixtures in tests/golden/ (made by
+tools/make_golden.py).
+
+Everything is plain numpy, float32 unless a line says float64.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+SAMPLE_RATE = 16000
+N_FFT = 400
+HOP = 160
+CHUNK_SAMPLES = 480000
+N_FRAMES = 3000
+
+
+# ----------------------------------------------------------------------------
+# log-mel front end
+# ----------------------------------------------------------------------------
+def _hz_to_mel_slaney(f):
+    # transformers audio_utils.py:470-481
+    f = np.asarray(f, dtype=np.float64)
+    mels = 3.0 * f / 200.0
+    logstep = 27.0 / np.log(6.4)
+    big = f >= 1000.0
+    return np.where(big, 15.0 + np.log(np.maximum(f, 1e-300) / 1000.0) * logstep, mels)
+
+
+def _mel_to_hz_slaney(m):
+    # transformers audio_utils.py:506-517
+    m = np.asarray(m, dtype=np.float64)
+    f = 200.0 * m / 3.0
+    logstep = np.log(6.4) / 27.0
+    big = m >= 15.0
+    return np.where(big, 1000.0 * np.exp(logstep * (m - 15.0)), f)
+
+
+def mel_filter_bank(n_mels: int) -> np.ndarray:
+    """[201, n_mels] float64 slaney-scale, slaney-normalised triangles over 0..8000 Hz.
+
+    transformers feature_extraction_whisper.py:95-103, audio_utils.py:638-729,541-560.
+    """
+    mel_pts = np.linspace(_hz_to_mel_slaney(0.0), _hz_to_mel_slaney(8000.0), n_mels + 2)
+    hz_pts = _mel_to_hz_slaney(mel_pts)
+    fft_freqs = np.linspace(0, SAMPLE_RATE // 2, N_FFT // 2 + 1)
+    diff = np.diff(hz_pts)
+    slopes = hz_pts[None, :] - fft_freqs[:, None]
+    down = -slopes[:, :-2] / diff[:-1]
+    up = slopes[:, 2:] / diff[1:]
+    fb = np.maximum(0.0, np.minimum(down, up))
+    enorm = 2.0 / (hz_pts[2:n_mels + 2] - hz_pts[:n_mels])
+    return fb * enorm[None, :]
+
+
+def hann_periodic(n: int = N_FFT) -> np.ndarray:
+    # torch.hann_window(n) (periodic) — feature_extraction_whisper.py:141
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n, dtype=np.float64) / n)
+
+
+def log_mel(pcm: np.ndarray, n_mels: int) -> np.ndarray:
+    """pcm float32 [B, 480000] -> float32 [B, n_mels, 3000].
+
+    transformers feature_extraction_whisper.py:140-165: centred STFT with
+    reflect padding of 200, periodic Hann, power spectrum, last frame dropped,
+    mel filters, log10 clamped at 1e-10, floor at (per-chunk max - 8), (x+4)/4.
+    The DFT is carried in float64 here and rounded to float32 at the power
+    spectrum; the float32 FFT of the cited code agrees to ~1e-6 on the output.
+    """
+    pcm = np.asarray(pcm, dtype=np.float32)
+    if pcm.ndim == 1:
+        pcm = pcm[None]
+    B, n = pcm.shape
+    assert n == CHUNK_SAMPLES
+    win = hann_periodic()
+    filt = mel_filter_bank(n_mels).astype(np.float32)          # cast as :156
+    out = np.empty((B, n_mels, N_FRAMES), dtype=np.float32)
+    idx = np.arange(N_FFT)[None, :] + HOP * np.arange(N_FRAMES)[:, None]
+    for b in range(B):
+        x = np.pad(pcm[b].astype(np.float64), N_FFT // 2, mode="reflect")
+        frames = x[idx] * win[None, :]
+        spec = np.fft.rfft(frames, axis=1)                      # [3000, 201]
+        power = (spec.real ** 2 + spec.imag ** 2).astype(np.float32)
+        mel = filt.T @ power.T                                   # [n_mels, 3000]
+        logs = np.log10(np.maximum(mel, np.float32(1e-10)))
+        logs = np.maximum(logs, logs.max() - np.float32(8.0))
+        out[b] = (logs + np.float32(4.0)) / np.float32(4.0)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# transformer pieces
+# ----------------------------------------------------------------------------
+_erf = np.vectorize(math.erf, otypes=[np.float64])
+
+
+def gelu(x: np.ndarray) -> np.ndarray:
+    """Exact (erf) GELU, as nn.functional.gelu default (modeling_whisper.py:618-619,403)."""
+    try:
+        from scipy.special import erf
+        return (0.5 * x * (1.0 + erf(x * np.float32(0.7071067811865476)))).astype(np.float32)
+    except ImportError:                                          # pragma: no cover
+        return (0.5 * x * (1.0 + _erf(x / math.sqrt(2.0)))).astype(np.float32)
+
+
+def layer_norm(x, g, b, eps=1e-5):
+    mu = x.mean(axis=-1, keepdims=True, dtype=np.float32)
+    xc = x - mu
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=np.float32)
+    return (xc / np.sqrt(var + np.float32(eps)) * g + b).astype(np.float32)
+
+
+def linear(x, w, b=None):
+    y = x @ w.T
+    if b is not None:
+        y = y + b
+    return y.astype(np.float32)
+
+
+def softmax(s):
+    s = s - s.max(axis=-1, keepdims=True)
+    e = np.exp(s)
+    return (e / e.sum(axis=-1, keepdims=True)).astype(np.float32)
+
+
+def _split_heads(x, h):
+    B, T, D = x.shape
+    return x.reshape(B, T, h, D // h).transpose(0, 2, 1, 3)     # [B,h,T,hd]
+
+
+def _merge_heads(x):
+    B, h, T, hd = x.shape
+    return x.transpose(0, 2, 1, 3).reshape(B, T, h * hd)
+
+
+class WhisperOracle:
+    """fp32 Whisper forward with Hugging Face state-dict names.
+
+    ``w``: dict name -> float32 ndarray (``proj_out.weight`` is tied to
+    ``model.decoder.embed_tokens.weight`` — modeling_whisper.py:965,970,1080).
+    """
+
+    def __init__(self, dims, weights: dict):
+        self.d = dims
+        self.w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
+        self.H = dims.n_heads
+        self.scale = np.float32((dims.d_model // dims.n_heads) ** -0.5)
+
+    # -- attention (modeling_whisper.py:241-356,215-238) -----------------------
+    def _attn_proj(self, p, x, kv_src):
+        w = self.w
+        q = linear(x, w[p + ".q_proj.weight"], w[p + ".q_proj.bias"]) * self.scale   # :309 scale BEFORE QK^T
+        k = linear(kv_src, w[p + ".k_proj.weight"])                                   # :279 no bias
+        v = linear(kv_src, w[p + ".v_proj.weight"], w[p + ".v_proj.bias"])
+        return _split_heads(q, self.H), _split_heads(k, self.H), _split_heads(v, self.H)
+
+    def _attn_core(self, p, q, k, v, mask=None):
+        s = q @ k.transpose(0, 1, 3, 2)
+        if mask is not None:
+            s = s + mask
+        o = softmax(s) @ v
+        w = self.w
+        return linear(_merge_heads(o), w[p + ".out_proj.weight"], w[p + ".out_proj.bias"])
+
+    # -- encoder (modeling_whisper.py:555-646,360-413) -------------------------
+    def conv_stem(self, mel):
+        w = self.w
+        e = "model.encoder"
+        B = mel.shape[0]
+        x = np.pad(mel, ((0, 0), (0, 0), (1, 1)))
+        w1 = w[e + ".conv1.weight"]                               # [D, n_mels, 3]
+        T = mel.shape[2]
+        h = sum(np.einsum("bct,dc->bdt", x[:, :, j:j + T], w1[:, :, j], optimize=True) for j in range(3))
+        h = gelu(h + w[e + ".conv1.bias"][None, :, None])         # [B, D, 3000]
+        x2 = np.pad(h, ((0, 0), (0, 0), (1, 1)))
+        w2 = w[e + ".conv2.weight"]
+        T2 = T // 2
+        h2 = sum(np.einsum("bct,dc->bdt", x2[:, :, j:j + 2 * T2:2], w2[:, :, j], optimize=True) for j in range(3))
+        h2 = gelu(h2 + w[e + ".conv2.bias"][None, :, None])       # [B, D, 1500]
+        return (h2.transpose(0, 2, 1) + w[e + ".embed_positions.weight"][None]).astype(np.float32)
+
+    def encoder_layer(self, i, x):
+        w = self.w
+        p = f"model.encoder.layers.{i}"
+        h = layer_norm(x, w[p + ".self_attn_layer_norm.weight"], w[p + ".self_attn_layer_norm.bias"])
+        q, k, v = self._attn_proj(p + ".self_attn", h, h)
+        x = x + self._attn_core(p + ".self_attn", q, k, v)
+        h = layer_norm(x, w[p + ".final_layer_norm.weight"], w[p + ".final_layer_norm.bias"])
+        h = gelu(linear(h, w[p + ".fc1.weight"], w[p + ".fc1.bias"]))
+        return (x + linear(h, w[p + ".fc2.weight"], w[p + ".fc2.bias"])).astype(np.float32)
+
+    def encode(self, mel):
+        x = self.conv_stem(np.asarray(mel, dtype=np.float32))
+        for i in range(self.d.enc_layers):
+            x = self.encoder_layer(i, x)
+        w = self.w
+        return layer_norm(x, w["model.encoder.layer_norm.weight"], w["model.encoder.layer_norm.bias"])
+
+    # -- decoder (modeling_whisper.py:666-795,416-505) -------------------------
+    def cross_kv(self, enc):
+        """Per decoder layer (K, V) over the encoder output, computed once (:321-335)."""
+        out = []
+        w = self.w
+        for i in range(self.d.dec_layers):
+            p = f"model.decoder.layers.{i}.encoder_attn"
+            k = _split_heads(linear(enc, w[p + ".k_proj.weight"]), self.H)
+            v = _split_heads(linear(enc, w[p + ".v_proj.weight"], w[p + ".v_proj.bias"]), self.H)
+            out.append((k, v))
+        return out
+
+    def decoder_step(self, tokens, pos, self_cache, cross):
+        """One position for the whole batch.
+
+        tokens int [B]; pos = index of this token; self_cache: list per layer of
+        [K, V] arrays [B,h,t,hd] that this call extends; returns logits f32 [B, vocab].
+        """
+        w = self.w
+        q_ = "model.decoder"
+        x = (w[q_ + ".embed_tokens.weight"][tokens] + w[q_ + ".embed_positions.weight"][pos][None, :])[:, None, :]
+        x = x.astype(np.float32)
+        for i in range(self.d.dec_layers):
+            p = f"{q_}.layers.{i}"
+            h = layer_norm(x, w[p + ".self_attn_layer_norm.weight"], w[p + ".self_attn_layer_norm.bias"])
+            q, k, v = self._attn_proj(p + ".self_attn", h, h)
+            if self_cache[i] is None:
+                self_cache[i] = [k, v]
+            else:
+                self_cache[i][0] = np.concatenate([self_cache[i][0], k], axis=2)
+                self_cache[i][1] = np.concatenate([self_cache[i][1], v], axis=2)
+            # a single new query sees every cached position: the causal mask is all-visible
+            x = x + self._attn_core(p + ".self_attn", q, self_cache[i][0], self_cache[i][1])
+            h = layer_norm(x, w[p + ".encoder_attn_layer_norm.weight"], w[p + ".encoder_attn_layer_norm.bias"])
+            pc = p + ".encoder_attn"
+            qc = _split_heads(linear(h, w[pc + ".q_proj.weight"], w[pc + ".q_proj.bias"]) * self.scale, self.H)
+            x = x + self._attn_core(pc, qc, cross[i][0], cross[i][1])
+            h = layer_norm(x, w[p + ".final_layer_norm.weight"], w[p + ".final_layer_norm.bias"])
+            h = gelu(linear(h, w[p + ".fc1.weight"], w[p + ".fc1.bias"]))
+            x = (x + linear(h, w[p + ".fc2.weight"], w[p + ".fc2.bias"])).astype(np.float32)
+        x = layer_norm(x, w[q_ + ".layer_norm.weight"], w[q_ + ".layer_norm.bias"])
+        return linear(x[:, 0, :], w[q_ + ".embed_tokens.weight"])          # tied, no bias
+
+    # -- greedy search ----------------------------------------------------------
+    def greedy(self, enc, prompt, max_new, eot, suppress=(), begin_suppress=(), return_logits=False):
+        """Greedy decoding with token rules.
+
+        prompt: list of forced ids (the same for every sequence).  The first sampled
+        position additionally masks ``begin_suppress`` (blank / EOT at the start,
+        cf. transformers configuration_whisper.py:153); ``suppress`` is masked at every
+        sampled position (non-speech set, configuration_whisper.py:34-44).  A sequence
+        stops at ``eot``; afterwards it is padded with ``eot``.  Ties resolve to the
+        lowest id.  Returns (ids int32 [B, max_new], lengths int32 [B], logits or None)
+        where lengths count tokens before the EOT.
+        """
+        enc = np.asarray(enc, dtype=np.float32)
+        B = enc.shape[0]
+        assert len(prompt) >= 1 and len(prompt) + max_new <= self.d.n_text_ctx
+        cross = self.cross_kv(enc)
+        cache = [None] * self.d.dec_layers
+        sup = np.zeros(self.d.vocab, dtype=bool)
+        sup[list(suppress)] = True
+        bsup = sup.copy()
+        bsup[list(begin_suppress)] = True
+        ids = np.full((B, max_new), eot, dtype=np.int32)
+        lens = np.full(B, -1, dtype=np.int32)
+        all_logits = []
+        tok = None
+        for pos, t in enumerate(prompt):
+            tok = np.full(B, t, dtype=np.int64)
+            logits = self.decoder_step(tok, pos, cache, cross)
+        pos = len(prompt)
+        for n in range(max_new):
+            if return_logits:
+                all_logits.append(logits.copy())
+            masked = np.where((bsup if n == 0 else sup)[None, :], -np.inf, logits)
+            nxt = masked.argmax(axis=1)
+            done = lens >= 0
+            nxt = np.where(done, eot, nxt)
+            ids[:, n] = nxt
+            newly = (~done) & (nxt == eot)
+            lens[newly] = n
+            if (lens >= 0).all() or n == max_new - 1:
+                break
+            logits = self.decoder_step(nxt.astype(np.int64), pos, cache, cross)
+            pos += 1
+        lens[lens < 0] = max_new
+        return ids, lens, (np.stack(all_logits) if return_logits else None)
+
+    def forced_logits(self, enc, tokens):
+        """Teacher-forced logits: tokens int [B, n] -> f32 [B, n, vocab]."""
+        enc = np.asarray(enc, dtype=np.float32)
+        tokens = np.asarray(tokens)
+        cross = self.cross_kv(enc)
+        cache = [None] * self.d.dec_layers
+        outs = [self.decoder_step(tokens[:, j].astype(np.int64), j, cache, cross) for j in range(tokens.shape[1])]
+        return np.stack(outs, axis=1)
+
+    # -- whole path ---------------------------------------------------------------
+    def transcribe_ids(self, pcm, prompt, max_new, eot, suppress=(), begin_suppress=()):
+        mel = log_mel(pcm, self.d.n_mels)
+        enc = self.encode(mel)
+        ids, lens, _ = self.greedy(enc, prompt, max_new, eot, suppress, begin_suppress)
+        return ids, lens

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the Hugging Face Whisper implementation.
+
+Run in the build container only (it imports ``transformers``, which does not
+travel to the GPU box).  For each configuration it builds
+``WhisperForConditionalGeneration`` from a locally constructed config, loads
+the repository's deterministic synthetic weights, and records small slices of
+every stage's output: log-mel, encoder output, teacher-forced logits, and the
+greedy token ids with their top-1 margins.  The numpy oracle and the HIP path
+are both tested against these files.
+
+    python tools/make_golden.py            # micro + tiny
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import manual_whisper_amd as mw                      # noqa: E402
+from manual_whisper_amd import synth                 # noqa: E402
+from manual_whisper_amd.decode_options import synthetic_options   # noqa: E402
+
+
+def build_hf(dims, weights):
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    cfg = WhisperConfig(
+        vocab_size=dims.vocab, num_mel_bins=dims.n_mels, d_model=dims.d_model,
+        encoder_layers=dims.enc_layers, decoder_layers=dims.dec_layers,
+        encoder_attention_heads=dims.n_heads, decoder_attention_heads=dims.n_heads,
+        encoder_ffn_dim=dims.ffn_dim, decoder_ffn_dim=dims.ffn_dim,
+        max_source_positions=dims.n_audio_ctx, max_target_positions=dims.n_text_ctx,
+        activation_function="gelu", dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+        pad_token_id=0, bos_token_id=1, eos_token_id=2, decoder_start_token_id=1,
+        suppress_tokens=None, begin_suppress_tokens=None,
+    )
+    cfg._attn_implementation = "eager"
+    model = WhisperForConditionalGeneration(cfg).eval().float()
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("proj_out" in m for m in missing), missing
+    return model
+
+
+def hf_mel(pcm, n_mels):
+    from transformers import WhisperFeatureExtractor
+    fe = WhisperFeatureExtractor(feature_size=n_mels)
+    return fe._torch_extract_fbank_features(pcm.copy()).astype(np.float32)
+
+
+@torch.no_grad()
+def hf_greedy(model, enc, opts, max_new):
+    """Manual greedy loop over the KV-cached HF decoder (no generate())."""
+    B = enc.shape[0]
+    enc_t = torch.from_numpy(enc)
+    from transformers.modeling_outputs import BaseModelOutput
+    eo = BaseModelOutput(last_hidden_state=enc_t)
+    past = None
+    prompt = torch.tensor([opts.prompt] * B, dtype=torch.long)
+    out = model(encoder_outputs=eo, decoder_input_ids=prompt, past_key_values=past, use_cache=True)
+    past = out.past_key_values
+    logits = out.logits[:, -1].numpy()
+    prompt_logits = out.logits.numpy().copy()
+    sup = np.zeros(logits.shape[1], bool)
+    sup[list(opts.suppress)] = True
+    bsup = sup.copy()
+    bsup[list(opts.begin_suppress)] = True
+    ids = np.full((B, max_new), opts.eot, np.int32)
+    lens = np.full(B, -1, np.int32)
+    margins = np.zeros((B, max_new), np.float32)
+    step_logits = []
+    for n in range(max_new):
+        step_logits.append(logits.copy())
+        masked = np.where((bsup if n == 0 else sup)[None], -np.inf, logits)
+        nxt = masked.argmax(1)
+        top2 = np.partition(masked, -2, axis=1)[:, -2:]
+        margins[:, n] = top2[:, 1] - top2[:, 0]
+        done = lens >= 0
+        nxt = np.where(done, opts.eot, nxt)
+        ids[:, n] = nxt
+        lens[(~done) & (nxt == opts.eot)] = n
+        if (lens >= 0).all() or n == max_new - 1:
+            break
+        out = model(encoder_outputs=eo, decoder_input_ids=torch.from_numpy(nxt)[:, None].long(),
+                    past_key_values=past, use_cache=True)
+        past = out.past_key_values
+        logits = out.logits[:, -1].numpy()
+    lens[lens < 0] = max_new
+    return ids, lens, margins, np.stack(step_logits), prompt_logits
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    for name, B, max_new in (("micro", 2, 24), ("tiny", 2, 12)):
+        dims = mw.get_dims(name)
+        weights = synth.make_weights_np(dims, seed=1234)
+        pcm = synth.make_pcm_np(B, seed=0)
+        opts = synthetic_options(dims)
+        model = build_hf(dims, weights)
+        mel = hf_mel(pcm, dims.n_mels)
+        with torch.no_grad():
+            enc = model.model.encoder(torch.from_numpy(mel)).last_hidden_state.numpy()
+        ids, lens, margins, step_logits, prompt_logits = hf_greedy(model, enc, opts, max_new)
+        topk = 8
+        order = np.argsort(-step_logits, axis=2)[:, :, :topk]
+        topv = np.take_along_axis(step_logits, order, axis=2)
+        # a fixed, strided probe of logits columns pins values away from the top too
+        probe_cols = np.arange(0, dims.vocab, max(1, dims.vocab // 64))[:64]
+        np.savez_compressed(
+            os.path.join(outdir, f"{name}.npz"),
+            config=np.array(name), seed=np.array(1234), pcm_seed=np.array(0), batch=np.array(B),
+            mel_sub=mel[:, :, ::16], mel_max=mel.max(axis=(1, 2)), mel_mean=mel.mean(axis=(1, 2)),
+            enc_sub=enc[:, ::25, :], enc_absmean=np.abs(enc).mean(),
+            prompt=np.array(opts.prompt, np.int32), eot=np.array(opts.eot),
+            suppress=np.array(opts.suppress, np.int32), begin_suppress=np.array(opts.begin_suppress, np.int32),
+            ids=ids, lens=lens, margins=margins,
+            top_idx=order.astype(np.int32), top_val=topv.astype(np.float32),
+            probe_cols=probe_cols.astype(np.int32), probe_val=step_logits[:, :, probe_cols].astype(np.float32),
+            prompt_probe=prompt_logits[:, :, probe_cols].astype(np.float32),
+            logit_std=np.array(step_logits.std(), np.float32),
+        )
+        print(f"{name}: ids[0]={ids[0][:12]} lens={lens} min margin={margins[margins > 0].min():.4f} "
+              f"logit std={step_logits.std():.3f} enc |mean|={np.abs(enc).mean():.3f}")
+
+
+if __name__ == "__main__":
+    main()
