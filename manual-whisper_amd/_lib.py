@@ -34,6 +34,27 @@ class DecodeOpts(C.Structure):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7, the same soname
+    libmwhip.so asks for).  Two HIP/HSA runtimes in one process cannot both own the GPU: whichever
+    initialises second sees no devices.  So when torch is installed its bundled runtime is loaded
+    first, by path; libmwhip.so then binds to it through the soname, and a later ``import torch``
+    finds the very same file already mapped.  Without torch the system ROCm runtime is used.
+    """
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -41,6 +62,7 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m manual_whisper_amd.build` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p
     lib.mw_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.c_int, C.POINTER(vp)]

@@ -160,3 +160,16 @@ def make_pcm_np(batch: int, seed: int = 0, n: int = CHUNK_SAMPLES) -> np.ndarray
         tone = 0.05 * np.sin(2 * np.pi * f1 * t) + 0.03 * np.sin(2 * np.pi * f2 * t)
         rows.append(noise + tone.astype(np.float32))
     return np.stack(rows).astype(np.float32)
+
+
+def make_pcm_torch(batch: int, seed: int = 0, device="cpu", n: int = CHUNK_SAMPLES):
+    """Same construction as make_pcm_np, built on `device` (tones differ in the last float32 bit)."""
+    import torch
+    t = torch.arange(n, dtype=torch.float64, device=device) / 16000.0
+    rows = []
+    for b in range(batch):
+        noise = hash_uniform_torch(n, f"pcm.{b}", seed, device) * (0.1 * 2.0 * math.sqrt(3.0))
+        f1, f2 = 440.0 * (1 + 0.07 * b), 1000.0 * (1 + 0.03 * b)
+        tone = 0.05 * torch.sin(2 * math.pi * f1 * t) + 0.03 * torch.sin(2 * math.pi * f2 * t)
+        rows.append(noise + tone.to(torch.float32))
+    return torch.stack(rows).contiguous()

@@ -277,6 +277,7 @@ class WhisperOracle:
         bsup[list(begin_suppress)] = True
         ids = np.full((B, max_new), eot, dtype=np.int32)
         lens = np.full(B, -1, dtype=np.int32)
+        self.last_margins = np.full((B, max_new), np.inf, dtype=np.float32)   # top-1 minus top-2 per choice
         all_logits = []
         tok = None
         for pos, t in enumerate(prompt):
@@ -288,6 +289,8 @@ class WhisperOracle:
                 all_logits.append(logits.copy())
             masked = np.where((bsup if n == 0 else sup)[None, :], -np.inf, logits)
             nxt = masked.argmax(axis=1)
+            top2 = np.partition(masked, -2, axis=1)[:, -2:]
+            self.last_margins[:, n] = top2[:, 1] - top2[:, 0]
             done = lens >= 0
             nxt = np.where(done, eot, nxt)
             ids[:, n] = nxt

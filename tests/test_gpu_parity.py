@@ -1,0 +1,252 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the committed fixtures.
+
+Tolerances (fp16 operands, fp32 accumulation, against an fp32 oracle):
+  log-mel     abs 1e-4  (fp32 DFT-as-matmul vs float64 FFT)
+  encoder out abs 1e-2  (values are O(1) after the final LayerNorm)
+  logits      abs 3e-2  on logits of std ~2-3
+  greedy ids  identical on the fixtures (their top-1 margins are recorded in the .npz)
+"""
+import os
+
+import numpy as np
+import pytest
+
+import manual_whisper_amd as mw
+from manual_whisper_amd import synth
+from manual_whisper_amd.decode_options import DecodeOptions, synthetic_options
+from oracle.whisper_ref import WhisperOracle, log_mel
+
+pytestmark = pytest.mark.gpu
+
+MEL_ATOL = 1e-4
+ENC_ATOL = 1e-2
+LOGIT_ATOL = 3e-2
+
+
+TIE_GAP = 2e-2      # an oracle top-1/top-2 gap below this may legitimately flip under fp16 rounding
+
+
+def assert_ids_match_up_to_ties(ids, want, margins):
+    """Identical ids, except that a sequence may leave the oracle's path at a position where the
+    oracle's own top-2 gap is below TIE_GAP (everything after such a flip is a different, equally
+    valid greedy path and is not compared)."""
+    for b in range(ids.shape[0]):
+        diff = np.nonzero(ids[b] != want[b])[0]
+        if diff.size:
+            n = int(diff[0])
+            assert margins[b, n] < TIE_GAP, f"sequence {b} diverges at token {n} where the oracle margin is {margins[b, n]:.4f}"
+
+
+def _engine(dims, weights, max_batch=4):
+    from manual_whisper_amd.engine import Engine
+    eng = Engine(dims, device=0, max_batch=max_batch)
+    eng.load_weights(weights)
+    return eng
+
+
+@pytest.fixture(scope="module", params=["micro", "tiny"])
+def setup(request, golden_dir):
+    g = np.load(os.path.join(golden_dir, request.param + ".npz"))
+    dims = mw.get_dims(request.param)
+    w = synth.make_weights_np(dims, int(g["seed"]))
+    B = int(g["batch"])
+    pcm = synth.make_pcm_np(B, int(g["pcm_seed"]))
+    orc = WhisperOracle(dims, w)
+    mel_ref = log_mel(pcm, dims.n_mels)
+    enc_ref = orc.encode(mel_ref)
+    eng = _engine(dims, w)
+    yield dict(g=g, dims=dims, w=w, B=B, pcm=pcm, orc=orc, mel_ref=mel_ref, enc_ref=enc_ref, eng=eng)
+    eng.close()
+
+
+def test_logmel_vs_oracle_and_fixture(setup):
+    mel = setup["eng"].logmel(setup["pcm"])
+    assert np.abs(mel - setup["mel_ref"]).max() < MEL_ATOL
+    np.testing.assert_allclose(mel[:, :, ::16], setup["g"]["mel_sub"], atol=MEL_ATOL, rtol=0)
+
+
+def test_encoder_vs_oracle_and_fixture(setup):
+    enc = setup["eng"].encode(setup["B"], mel=setup["mel_ref"])
+    assert np.abs(enc - setup["enc_ref"]).max() < ENC_ATOL
+    np.testing.assert_allclose(enc[:, ::25, :], setup["g"]["enc_sub"], atol=ENC_ATOL, rtol=0)
+
+
+def test_forced_logits_vs_oracle(setup):
+    eng, orc, g, B = setup["eng"], setup["orc"], setup["g"], setup["B"]
+    eng.encode(B, mel=setup["mel_ref"], want_output=False)
+    rng = np.random.default_rng(5)
+    tail = rng.integers(0, setup["dims"].vocab, size=(B, 6))
+    toks = np.concatenate([np.tile(np.asarray(g["prompt"])[None], (B, 1)), tail], axis=1).astype(np.int32)
+    got = eng.decode_forced(toks)
+    want = orc.forced_logits(setup["enc_ref"], toks)
+    assert np.abs(got - want).max() < LOGIT_ATOL
+    P = len(g["prompt"])
+    np.testing.assert_allclose(got[:, :P][:, :, g["probe_cols"]], g["prompt_probe"], atol=LOGIT_ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_greedy_ids_identical_to_fixture(setup, graph):
+    eng, g, B = setup["eng"], setup["g"], setup["B"]
+    max_new = g["ids"].shape[1]
+    eng.set_option("graph", graph)
+    eng.set_decode_options(DecodeOptions(tuple(int(t) for t in g["prompt"]), int(g["eot"]), tuple(int(t) for t in g["suppress"]),
+                                         tuple(int(t) for t in g["begin_suppress"]), max_new))
+    eng.encode(B, mel=setup["mel_ref"], want_output=False)
+    ids, lens, logits = eng.decode_greedy(B, want_logits=True)
+    assert (ids == g["ids"]).all(), (ids, g["ids"], g["margins"].min())
+    assert (lens == g["lens"]).all()
+    got_top = np.take_along_axis(logits, g["top_idx"], 2)
+    np.testing.assert_allclose(got_top, g["top_val"], atol=LOGIT_ATOL, rtol=0)
+    eng.set_option("graph", 1)
+
+
+def test_whole_path_from_pcm(setup):
+    """mw_transcribe_batch (features computed on the GPU too) gives the fixture's ids."""
+    eng, g = setup["eng"], setup["g"]
+    max_new = g["ids"].shape[1]
+    eng.set_decode_options(DecodeOptions(tuple(int(t) for t in g["prompt"]), int(g["eot"]), tuple(int(t) for t in g["suppress"]),
+                                         tuple(int(t) for t in g["begin_suppress"]), max_new))
+    ids, lens = eng.transcribe_batch(setup["pcm"])
+    assert (ids == g["ids"]).all() and (lens == g["lens"]).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases and size-independent properties
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def micro():
+    dims = mw.get_dims("micro")
+    w = synth.make_weights_np(dims, 4321)
+    eng = _engine(dims, w, max_batch=16)
+    yield dims, w, eng
+    eng.close()
+
+
+def test_logmel_edge_inputs(micro):
+    """Silence (every value hits the 1e-10 clamp), full-scale square wave, a click at the very first
+    and last sample (reflect padding), and a ramp."""
+    dims, _, eng = micro
+    n = 480000
+    pcm = np.zeros((5, n), np.float32)
+    pcm[1] = np.where((np.arange(n) // 40) % 2 == 0, 1.0, -1.0)
+    pcm[2, 0] = 1.0
+    pcm[2, -1] = -1.0
+    pcm[3] = np.linspace(-1, 1, n, dtype=np.float32)
+    pcm[4] = synth.make_pcm_np(1, 9)[0] * 1e-4
+    got = eng.logmel(pcm)
+    want = log_mel(pcm, dims.n_mels)
+    assert np.isfinite(got).all()
+    assert (got[0] == got[0, 0, 0]).all() and abs(got[0, 0, 0] - want[0, 0, 0]) < 1e-6     # silence: (-10+4)/4
+    # Rows with exact cancellation (silence aside) leave bins far below the -8 floor, where float32
+    # and float64 spectra differ by orders of magnitude before the clamp hides them.
+    assert np.abs(got - want).max() < 5e-4
+
+
+def test_batch_invariance_and_determinism(micro):
+    """A chunk's ids do not depend on its batch position, batch size or run (no atomics anywhere)."""
+    dims, w, eng = micro
+    opts = synthetic_options(dims, max_new=10)
+    eng.set_decode_options(opts)
+    pcm = synth.make_pcm_np(16, seed=11)
+    ids16, lens16 = eng.transcribe_batch(pcm)
+    ids16b, _ = eng.transcribe_batch(pcm)
+    assert (ids16 == ids16b).all()
+    ids1, _ = eng.transcribe_batch(pcm[5:6])
+    assert (ids1[0] == ids16[5]).all()
+    perm = np.arange(15, -1, -1)
+    idsp, _ = eng.transcribe_batch(np.ascontiguousarray(pcm[perm]))
+    assert (idsp == ids16[perm]).all()
+    ids3, _ = eng.transcribe_batch(pcm[3:6])
+    assert (ids3 == ids16[3:6]).all()
+
+
+def test_full_batch_matches_oracle(micro):
+    dims, w, eng = micro
+    opts = synthetic_options(dims, max_new=6)
+    eng.set_decode_options(opts)
+    pcm = synth.make_pcm_np(16, seed=21)
+    ids, lens = eng.transcribe_batch(pcm)
+    orc = WhisperOracle(dims, w)
+    want, wl = orc.transcribe_ids(pcm, list(opts.prompt), opts.max_new, opts.eot, opts.suppress, opts.begin_suppress)
+    assert_ids_match_up_to_ties(ids, want, orc.last_margins)
+    assert (ids == want).all(axis=1).sum() >= 14, "more than two of 16 sequences hit a near-tie"
+
+
+def test_long_prompt_and_max_positions(micro):
+    """A 200-token previous-text prompt and decoding up to the last text position (448)."""
+    dims, w, eng = micro
+    base = synthetic_options(dims, max_new=1)
+    prompt = tuple(int(t) for t in (np.arange(200) * 7 + 30) % (dims.vocab - 20)) + base.prompt
+    max_new = dims.n_text_ctx - len(prompt)
+    opts = DecodeOptions(prompt, base.eot, base.suppress, base.begin_suppress, max_new, suppress_eot=True)
+    eng.set_decode_options(opts)
+    pcm = synth.make_pcm_np(2, seed=31)
+    ids, lens = eng.transcribe_batch(pcm)
+    orc = WhisperOracle(dims, w)
+    want, wl = orc.transcribe_ids(pcm, list(prompt), max_new, opts.eot, opts.effective_suppress(), opts.begin_suppress)
+    assert (lens == max_new).all() and (wl == max_new).all()
+    assert_ids_match_up_to_ties(ids, want, orc.last_margins)
+
+
+def test_eot_stops_and_pads(micro):
+    """Suppress everything except EOT and one other id at the first sampled position only: the
+    sequence must stop as soon as EOT wins, lens = tokens before it, the rest padded with EOT."""
+    dims, w, eng = micro
+    eot = 77
+    allowed = {eot, 300}
+    sup = tuple(i for i in range(dims.vocab) if i not in allowed)
+    opts = DecodeOptions((1000, 1001), eot, sup, (), 12)
+    eng.set_decode_options(opts)
+    pcm = synth.make_pcm_np(3, seed=41)
+    ids, lens = eng.transcribe_batch(pcm)
+    orc = WhisperOracle(dims, w)
+    want, wl = orc.transcribe_ids(pcm, [1000, 1001], 12, eot, sup, ())
+    assert (ids == want).all() and (lens == wl).all()
+    for b in range(3):
+        assert set(ids[b, :lens[b]]) <= {300} and (ids[b, lens[b]:] == eot).all()
+
+
+def test_errors_are_reported_not_fatal(micro):
+    from manual_whisper_amd.engine import Engine, EngineError
+    dims, w, eng = micro
+    with pytest.raises(EngineError):
+        eng.logmel(np.zeros((17, 480000), np.float32))          # above max_batch
+    with pytest.raises(EngineError):
+        eng.logmel(np.zeros((1, 1000), np.float32))             # wrong chunk length
+    with pytest.raises(EngineError):
+        eng.decode_forced(np.full((1, 3), dims.vocab, np.int32))  # id out of range
+    e2 = Engine(dims, 0, 1)
+    with pytest.raises(EngineError, match="never set"):
+        e2.load_weights({k: v for k, v in w.items() if "fc2.bias" not in k})
+    e2.close()
+    e3 = Engine(dims, 0, 1)
+    with pytest.raises(EngineError, match="unknown tensor name"):
+        e3.load_weights({"model.encoder.bogus": np.zeros(3, np.float32)})
+    e3.close()
+    with pytest.raises(EngineError):
+        Engine(mw.WhisperDims("bad", 80, 100, 2, 1, 1, 256, 300), 0, 1)   # head_dim != 64
+
+
+def test_weight_dtypes_equivalent(micro):
+    """fp32, fp16 and bf16 inputs of the same values load to the same engine state."""
+    import torch
+    from manual_whisper_amd.engine import Engine
+    dims, w, eng = micro
+    opts = synthetic_options(dims, max_new=6)
+    eng.set_decode_options(opts)
+    pcm = synth.make_pcm_np(1, seed=51)
+    ref_ids, _ = eng.transcribe_batch(pcm)
+    wt = {k: torch.from_numpy(v).half() if v.ndim > 1 else torch.from_numpy(v) for k, v in w.items()}
+    e2 = Engine(dims, 0, 1)
+    e2.load_weights(wt)
+    e2.set_decode_options(opts)
+    ids, _ = e2.transcribe_batch(pcm)
+    e2.close()
+    assert (ids == ref_ids).all()
+    wg = {k: v.cuda() for k, v in wt.items()}                     # device-resident tensors
+    e3 = Engine(dims, 0, 1)
+    e3.load_weights(wg)
+    e3.set_decode_options(opts)
+    ids, _ = e3.transcribe_batch(torch.from_numpy(pcm).cuda())    # device-resident audio
+    e3.close()
+    assert (ids == ref_ids).all()
