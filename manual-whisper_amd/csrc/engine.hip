@@ -237,7 +237,7 @@ extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, m
     *out = nullptr;
     const mw_model_desc& d = *desc;
     if (d.d_model <= 0 || d.n_heads <= 0 || d.d_model != d.n_heads * kHeadDim) { g_create_error = "mw_create: head_dim must be 64"; return MW_ERR_ARG; }
-    if (d.d_model % 32 || d.ffn_dim % 32 || d.d_model > 2048) { g_create_error = "mw_create: d_model/ffn_dim must be multiples of 32, d_model <= 2048"; return MW_ERR_ARG; }
+    if (d.d_model % 32 || d.ffn_dim % 32 || d.d_model > 2048 || d.ffn_dim > 5120) { g_create_error = "mw_create: d_model/ffn_dim must be multiples of 32, d_model <= 2048, ffn_dim <= 5120"; return MW_ERR_ARG; }
     if (d.n_mels % 8 || d.n_mels > 128 || d.n_mels <= 0) { g_create_error = "mw_create: n_mels must be a multiple of 8, <= 128"; return MW_ERR_ARG; }
     if (d.n_audio_ctx != kFrames / 2 || d.n_text_ctx <= 0 || d.n_text_ctx > 448) { g_create_error = "mw_create: n_audio_ctx must be 1500 and n_text_ctx <= 448"; return MW_ERR_ARG; }
     if (max_batch < 1 || max_batch > 32) { g_create_error = "mw_create: max_batch must be in 1..32"; return MW_ERR_ARG; }
@@ -257,6 +257,7 @@ extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, m
     if (r) return bail(r);
     r = build_mel_tables(ctx);
     if (r) return bail(r);
+    dec_kernels_prepare();
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "stream sync failed in mw_create"; return bail(MW_ERR_HIP); }
     *out = ctx;
     return MW_OK;
@@ -632,7 +633,7 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
     auto base = [&](int N, int K, const LinearW& w) {
         GemvParams p{};
         p.B = B; p.N = N; p.K = K; p.W = w.w; p.bias = w.b; p.scale = 1.f; p.scale_ncols = 0; p.gelu = 0;
-        p.H = H; p.D = D; p.Tctx = Tc; p.st = ctx->st;
+        p.H = H; p.D = D; p.Tctx = Tc; p.st = ctx->st; p.ln_scratch = ctx->dxn; p.nv = 16;
         return p;
     };
     for (int li = 0; li < d.dec_layers; ++li) {
@@ -661,7 +662,8 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
         }
         {   GemvParams p = base(D, F, l.fc2); p.xin16 = ctx->dhid; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
     }
-    launch_layernorm(ctx->dx, ctx->dec_ln.g, ctx->dec_ln.b, ctx->dxn, nullptr, B, D, s);
+    // final LayerNorm; the same launch advances the position counter for the logits / finalize launches
+    launch_layernorm(ctx->dx, ctx->dec_ln.g, ctx->dec_ln.b, ctx->dxn, nullptr, B, D, s, &ctx->st->pos);
     {
         LinearW e{ctx->tok_emb, nullptr};
         GemvParams p = base(d.vocab, D, e);

@@ -3,9 +3,11 @@
 // captured hipGraph of a step is replayed for every token.
 //
 // Roofline: each kernel streams its weights (or the K/V cache) exactly once from HBM and does
-// O(batch) work per byte, so all are HBM/latency-bound; the matrix products still go through
-// v_mfma_f32_16x16x32_f16 (batch on the MFMA column index) because 16 FMAs per weight element on
-// the VALU would cost as much as the stream itself.
+// O(batch) work per byte, so all are HBM/latency-bound.  What decides their speed at batch 16 is
+// the number of DEPENDENT memory round trips per workgroup, so every kernel here issues all of its
+// global loads up front, branch-free (out-of-range pieces load a clamped, valid address and are
+// zeroed by a select afterwards), and only then starts to compute.  The matrix products go through
+// v_mfma_f32_16x16x32_f16 with the batch on the MFMA column index.
 #include "mw_kernels.h"
 
 namespace mw {
@@ -23,129 +25,162 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+__device__ __forceinline__ float half_wave_sum(float v) {      // over the 32 lanes that share lane>>5
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 
 // ------------------------------------------------------------------ skinny GEMM (weights streamed once)
 // out[b][n] = epi( sum_k X[b][k] * W[n][k] ),  b < B <= 16*MT.
-// Workgroup = 8 waves that split K; it owns NV (8 or 16) weight rows, so narrow outputs (N = d_model)
-// still spread over >= 160 workgroups.  Weight fragments go straight from global memory to the
-// MFMA A operand (no LDS: nothing is shared between waves); the activation fragment is the B
-// operand, read from L2, optionally through a fused LayerNorm (statistics computed per workgroup).
-// Partial sums of the 8 waves are combined through LDS in a fixed order: results are bit-for-bit
-// reproducible (no atomics).
-constexpr int GV_WAVES = 8;
-constexpr int GV_CH = 10;       // k-steps (of 32) whose loads are issued together
-
-template <int NV, int MT>
-__global__ __launch_bounds__(512) void gemv_kernel(GemvParams p) {
-    __shared__ float red[GV_WAVES][MT][64][4];
-    __shared__ float stat[16 * MT][2];
+//
+// Workgroup = NW waves that split K (wave w takes k-steps w, w+NW, ...; KPW of them, compile
+// time); it owns `nv` (8 or 16) weight rows, so narrow outputs still spread over >= 160
+// workgroups (with nv = 8 lanes 8..15 of each fragment re-read rows 0..7 from L1).  Weight
+// fragments go straight from global memory to the MFMA A operand; the activation fragment is the
+// B operand.  Plain input: fp16 activations, fetched with the weights.  LN input (XV > 0): the
+// fp32 residual rows are loaded once (32 lanes per row, XV float4 per lane), normalised in
+// registers (two-pass statistics, eps 1e-5) and staged in LDS as fp16 for all waves.
+// Partial sums of the waves are combined through LDS in a fixed order: bit-for-bit reproducible.
+template <int MT, int KPW, int XV>
+__global__ void gemv_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * NV;
-    int wrow = n0 + (NV == 16 ? fr : (fr & 7));
-    if (wrow >= p.N) wrow = p.N - 1;
+    const int nv = p.nv;
+    const int n0 = blockIdx.x * nv;
+    int wrow = n0 + (nv == 16 ? fr : (fr & 7));
+    wrow = min(wrow, p.N - 1);
     const f16* wp = p.W + (long)wrow * p.K + fg * 8;
+    const int nks = p.K >> 5;
 
-    const int nks = p.K / 32;
-    const int kpw = (nks + GV_WAVES - 1) / GV_WAVES;
-    const int ks0 = wave * kpw;
-    const int ks1 = min(ks0 + kpw, nks);
+    float4v* red = reinterpret_cast<float4v*>(smem);                       // [NW][MT][64]
+    char* after_red = smem + (size_t)NW * MT * 64 * 16;
 
-    // issue the first group of weight loads before anything that depends on the activations
-    uint4 wreg[GV_CH];
+    // ---- every global load of this workgroup is issued here
+    uint4 wreg[KPW];
+    bool kval[KPW];
 #pragma unroll
-    for (int c = 0; c < GV_CH; ++c)
-        wreg[c] = (ks0 + c < ks1) ? *reinterpret_cast<const uint4*>(wp + (ks0 + c) * 32) : make_uint4(0, 0, 0, 0);
+    for (int c = 0; c < KPW; ++c) {
+        const int ks = wave + NW * c;
+        kval[c] = ks < nks;
+        wreg[c] = *reinterpret_cast<const uint4*>(wp + min(ks, nks - 1) * 32);
+    }
+    // epilogue operands
+    const int nl = 4 * fg;
+    const int n = n0 + nl;
+    const bool owner = wave == 0 && nl < nv && n < p.N;                    // N is a multiple of 4
+    float4 bias4 = make_float4(0, 0, 0, 0);
+    float4 res4[MT];
+    if (owner) {
+        if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+        if (p.out_mode == GV_RESID) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                res4[t] = *reinterpret_cast<const float4*>(p.out32 + (long)min(t * 16 + fr, p.B - 1) * p.N + n);
+        }
+    }
 
-    const bool ln = p.ln_g != nullptr;
-    if (ln) {           // LayerNorm statistics of the B input rows (fp32, eps 1e-5)
-        for (int r = wave; r < p.B; r += GV_WAVES) {
-            const float* xr = p.x32 + (long)r * p.K;
+    half8 xfrag[MT][KPW];
+    if constexpr (XV == 0) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const f16* xr = p.xin16 + (long)min(t * 16 + fr, p.B - 1) * p.K + fg * 8;   // rows >= B: duplicates, never stored
+#pragma unroll
+            for (int c = 0; c < KPW; ++c) xfrag[t][c] = *reinterpret_cast<const half8*>(xr + min(wave + NW * c, nks - 1) * 32);
+        }
+    } else {
+        // LayerNorm of the fp32 rows: 32 lanes per row, NW*2 rows per pass
+        float* gam = reinterpret_cast<float*>(after_red);                  // [K]
+        float* bet = gam + p.K;                                            // [K]
+        f16* xs = reinterpret_cast<f16*>(bet + p.K);                       // [16*MT][K+8]
+        const int ldx = p.K + 8;
+        const int rows_per_pass = NW * 2;
+        const int l32 = tid & 31;
+        float4 v[XV];
+        auto load_rows = [&](int r0) {          // clamped addresses: no branch around any load
+            const float* xr = p.x32 + (long)min(r0 + (tid >> 5), p.B - 1) * p.K;
+#pragma unroll
+            for (int j = 0; j < XV; ++j) v[j] = *reinterpret_cast<const float4*>(xr + min(l32 * 4 + 128 * j, p.K - 4));
+        };
+        const int gi = min(tid * 4, p.K - 4);   // 512 threads x 4 >= K for every fused width
+        const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + gi);
+        const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b + gi);
+        load_rows(0);
+        *reinterpret_cast<float4*>(gam + gi) = g4;
+        *reinterpret_cast<float4*>(bet + gi) = b4;
+        __syncthreads();
+        for (int r0 = 0; r0 < 16 * MT; r0 += rows_per_pass) {
+            const int r = r0 + (tid >> 5);
+            if (r0 > 0) load_rows(r0);
             float s = 0.f;
-            for (int c = lane * 4; c < p.K; c += 256) {
-                const float4 v = *reinterpret_cast<const float4*>(xr + c);
-                s += v.x + v.y + v.z + v.w;
+#pragma unroll
+            for (int j = 0; j < XV; ++j) {
+                if (l32 * 4 + 128 * j >= p.K) v[j] = make_float4(0, 0, 0, 0);
+                s += v[j].x + v[j].y + v[j].z + v[j].w;
             }
-            const float mean = wave_sum(s) / p.K;
+            const float mean = half_wave_sum(s) / p.K;
             float q = 0.f;
-            for (int c = lane * 4; c < p.K; c += 256) {
-                const float4 v = *reinterpret_cast<const float4*>(xr + c);
-                const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
-                q += a * a + b * b + cc * cc + d * d;
+#pragma unroll
+            for (int j = 0; j < XV; ++j) {
+                if (l32 * 4 + 128 * j < p.K) {
+                    v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+                    q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+                }
             }
-            const float rstd = rsqrtf(wave_sum(q) / p.K + 1e-5f);
-            if (lane == 0) { stat[r][0] = mean; stat[r][1] = rstd; }
+            const float rstd = rsqrtf(half_wave_sum(q) / p.K + 1e-5f);
+            if (r < 16 * MT) {
+#pragma unroll
+                for (int j = 0; j < XV; ++j) {
+                    const int c = l32 * 4 + 128 * j;
+                    if (c < p.K) {
+                        const float4 g = *reinterpret_cast<const float4*>(gam + c);
+                        const float4 b = *reinterpret_cast<const float4*>(bet + c);
+                        *reinterpret_cast<half4*>(xs + r * ldx + c) =
+                            half4{(f16)(v[j].x * rstd * g.x + b.x), (f16)(v[j].y * rstd * g.y + b.y),
+                                  (f16)(v[j].z * rstd * g.z + b.z), (f16)(v[j].w * rstd * g.w + b.w)};
+                    }
+                }
+            }
         }
         __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int c = 0; c < KPW; ++c)
+                xfrag[t][c] = *reinterpret_cast<const half8*>(xs + (t * 16 + fr) * ldx + min(wave + NW * c, nks - 1) * 32 + fg * 8);
     }
 
     float4v acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = float4v{0, 0, 0, 0};
-
-    for (int kb = ks0; kb < ks1; kb += GV_CH) {
-        if (kb != ks0) {
 #pragma unroll
-            for (int c = 0; c < GV_CH; ++c)
-                wreg[c] = (kb + c < ks1) ? *reinterpret_cast<const uint4*>(wp + (kb + c) * 32) : make_uint4(0, 0, 0, 0);
-        }
+    for (int c = 0; c < KPW; ++c) {
+        uint4 w = wreg[c];
+        if (!kval[c]) w = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < GV_CH; ++c) {
-            if (kb + c < ks1) {
-                const int k = (kb + c) * 32 + fg * 8;
-#pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const int m = t * 16 + fr;
-                    half8 xf = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (m < p.B) {
-                        if (ln) {
-                            const float* xr = p.x32 + (long)m * p.K + k;
-                            const float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
-                            const float4 g0 = *reinterpret_cast<const float4*>(p.ln_g + k), g1 = *reinterpret_cast<const float4*>(p.ln_g + k + 4);
-                            const float4 b0 = *reinterpret_cast<const float4*>(p.ln_b + k), b1 = *reinterpret_cast<const float4*>(p.ln_b + k + 4);
-                            const float mu = stat[m][0], rs = stat[m][1];
-                            xf = half8{(f16)((a.x - mu) * rs * g0.x + b0.x), (f16)((a.y - mu) * rs * g0.y + b0.y),
-                                       (f16)((a.z - mu) * rs * g0.z + b0.z), (f16)((a.w - mu) * rs * g0.w + b0.w),
-                                       (f16)((b.x - mu) * rs * g1.x + b1.x), (f16)((b.y - mu) * rs * g1.y + b1.y),
-                                       (f16)((b.z - mu) * rs * g1.z + b1.z), (f16)((b.w - mu) * rs * g1.w + b1.w)};
-                        } else {
-                            xf = *reinterpret_cast<const half8*>(p.xin16 + (long)m * p.K + k);
-                        }
-                    }
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wreg[c]), xf, acc[t], 0, 0, 0);
-                }
-            }
-        }
+        for (int t = 0; t < MT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&w), xfrag[t][c], acc[t], 0, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < MT; ++t) *reinterpret_cast<float4v*>(&red[wave][t][lane][0]) = acc[t];
+    for (int t = 0; t < MT; ++t) red[(wave * MT + t) * 64 + lane] = acc[t];
     __syncthreads();
-    if (wave != 0) return;
+    if (!owner) return;
 
-    // ---- epilogue: lane holds out[m][n..n+3], n = n0 + 4*fg (rows 8..15 are duplicates when NV == 8)
-    const int nl = 4 * fg;
-    if (nl >= NV) return;
-    const int n = n0 + nl;
-    if (n >= p.N) return;                          // N is a multiple of 4 for every skinny GEMM
+    // ---- epilogue: lane holds out[m][n..n+3]
     const int pos = p.st ? p.st->pos : 0;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = t * 16 + fr;
         if (m >= p.B) continue;
-        float4v v = {0, 0, 0, 0};
-#pragma unroll
-        for (int w = 0; w < GV_WAVES; ++w) v += *reinterpret_cast<float4v*>(&red[w][t][lane][0]);
-        if (p.bias) {
-            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
+        float4v v = {bias4.x, bias4.y, bias4.z, bias4.w};
+        for (int w = 0; w < NW; ++w) v += red[(w * MT + t) * 64 + lane];
         if (n < p.scale_ncols) v *= p.scale;
         if (p.gelu) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
         if (p.out_mode == GV_RESID) {
-            float4* c = reinterpret_cast<float4*>(p.out32 + (long)m * p.N + n);
-            float4 o = *c;
-            o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
-            *c = o;
+            *reinterpret_cast<float4*>(p.out32 + (long)m * p.N + n) =
+                make_float4(res4[t].x + v[0], res4[t].y + v[1], res4[t].z + v[2], res4[t].w + v[3]);
         } else {
             const half4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
             if (p.out_mode == GV_F16) {
@@ -165,43 +200,65 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvParams p) {
 }
 
 // ------------------------------------------------------------------ logits + partial argmax
-// logits[b][n] = xn[b] . E[n] over the tied token embedding (modeling_whisper.py:1080); one wave
-// per 16 vocabulary rows with the full K, so no cross-wave reduction.  Each wave also reduces its
-// 16 columns to one (max, lowest index) candidate per sequence under the suppress mask that
-// applies to this position; dec_finalize picks the winner.
+// logits[b][n] = xn[b] . E[n] over the tied token embedding (modeling_whisper.py:1080).
+// Workgroup = 8 waves, each a tile of 16 vocabulary rows over the full K; the normalised
+// activations (fp16) are staged once per workgroup in LDS.  Weights stream through two register
+// banks of LCH k-steps so a bank's loads are in flight while the other feeds the MFMAs.  Each
+// workgroup also reduces its 128 columns to one (max, lowest index) candidate per sequence under
+// the suppress mask of this position; dec_finalize picks the winner.
+constexpr int LCH = 8;
 template <int MT>
-__global__ __launch_bounds__(256) void logits_kernel(GemvParams p) {
+__global__ __launch_bounds__(512) void logits_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* xs = reinterpret_cast<f16*>(smem);                                // [16*MT][K+8]
+    const int ldx = p.K + 8;
+    float* cand_v = reinterpret_cast<float*>(smem + (size_t)16 * MT * ldx * 2);   // [8][16*MT]
+    int* cand_i = reinterpret_cast<int*>(cand_v + 8 * 16 * MT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x * 8 + wave;
     const int n0 = tile * 16;
-    if (n0 >= p.N) return;
-    int wrow = n0 + fr;
-    if (wrow >= p.N) wrow = p.N - 1;
+    const int wrow = min(n0 + fr, p.N - 1);
     const f16* wp = p.W + (long)wrow * p.K + fg * 8;
+    const int nks = p.K >> 5;
+
+    uint4 wa[LCH], wb[LCH];
+    auto wload = [&](uint4 (&dst)[LCH], int kb) {
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) dst[c] = *reinterpret_cast<const uint4*>(wp + min(kb + c, nks - 1) * 32);
+    };
+    wload(wa, 0);
+    wload(wb, LCH);
+    for (int i = tid * 8; i < 16 * MT * p.K; i += blockDim.x * 8) {       // K is a multiple of 8
+        const int r = i / p.K, c = i - r * p.K;
+        *reinterpret_cast<uint4*>(xs + r * ldx + c) =
+            r < p.B ? *reinterpret_cast<const uint4*>(p.xin16 + (long)r * p.K + c) : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
     float4v acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = float4v{0, 0, 0, 0};
-    const int nks = p.K / 32;
-    for (int kb = 0; kb < nks; kb += 8) {
-        uint4 wreg[8];
+    auto consume = [&](uint4 (&src)[LCH], int kb) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            wreg[c] = (kb + c < nks) ? *reinterpret_cast<const uint4*>(wp + (kb + c) * 32) : make_uint4(0, 0, 0, 0);
+        for (int c = 0; c < LCH; ++c) {
+            uint4 w = src[c];
+            if (kb + c >= nks) w = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (kb + c < nks) {
-#pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const int m = t * 16 + fr;
-                    half8 xf = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (m < p.B) xf = *reinterpret_cast<const half8*>(p.xin16 + (long)m * p.K + (kb + c) * 32 + fg * 8);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wreg[c]), xf, acc[t], 0, 0, 0);
-                }
+            for (int t = 0; t < MT; ++t) {
+                const half8 xf = *reinterpret_cast<const half8*>(xs + (t * 16 + fr) * ldx + min(kb + c, nks - 1) * 32 + fg * 8);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&w), xf, acc[t], 0, 0, 0);
             }
         }
+    };
+    for (int kb = 0; kb < nks; kb += 2 * LCH) {
+        consume(wa, kb);
+        if (kb + 2 * LCH < nks) wload(wa, kb + 2 * LCH);
+        consume(wb, kb + LCH);
+        if (kb + 3 * LCH < nks) wload(wb, kb + 3 * LCH);
     }
-    const int sample = p.st->pos + 1 - p.st->prompt_len;       // index of the token chosen from these logits
+
+    const int sample = p.st->pos - p.st->prompt_len;       // pos was advanced by the final LayerNorm launch
     const uint8_t* mask = sample <= 0 ? p.mask_first : p.mask_rest;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -223,95 +280,91 @@ __global__ __launch_bounds__(256) void logits_kernel(GemvParams p) {
             const int oi = __shfl_xor(bidx, o);
             if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
         }
-        if (fg == 0 && m < p.B) {
-            p.part_val[(long)m * p.n_parts + tile] = best;
-            p.part_idx[(long)m * p.n_parts + tile] = bidx;
+        if (fg == 0) { cand_v[wave * 16 * MT + m] = best; cand_i[wave * 16 * MT + m] = bidx; }
+    }
+    __syncthreads();
+    if (tid < 16 * MT && tid < p.B) {
+        float best = cand_v[tid];
+        int bidx = cand_i[tid];
+        for (int w = 1; w < 8; ++w) {
+            const float ov = cand_v[w * 16 * MT + tid];
+            const int oi = cand_i[w * 16 * MT + tid];
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
         }
+        p.part_val[(long)tid * p.n_parts + blockIdx.x] = best;
+        p.part_idx[(long)tid * p.n_parts + blockIdx.x] = bidx;
     }
 }
 
 // ------------------------------------------------------------------ single-query attention over a cache
 // One workgroup per (sequence, head): scores over n keys ([n][64] fp16, contiguous), softmax, P.V.
 // Each 128-byte key/value row is fetched by 8 adjacent lanes (16 B each), 8 rows per wave
-// instruction, so every wave instruction reads 1 KiB of contiguous memory.
+// instruction, so every wave instruction reads 1 KiB of contiguous memory.  A thread owns RPT rows
+// (row = group + NG*i); all its K loads are issued together, and all its V loads are issued as
+// soon as the K registers are free, so V is in flight during the softmax.
 // Self-attention (modeling_whisper.py:473-478): n = position + 1, every cached key is visible to the
 // newest query.  Cross-attention (:486-492): n = 1500 encoder frames, K/V cached once (:313-326).
-template <int MAXT>
-__global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ kc,
-                                                       const f16* __restrict__ vc, f16* __restrict__ out, int H,
-                                                       int tstride, int nfixed, const DecState* __restrict__ st) {
-    __shared__ float sc[MAXT];
-    __shared__ float part[4][64];
-    __shared__ float red[8];
+template <int NT, int RPT>
+__global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ kc,
+                                                      const f16* __restrict__ vc, f16* __restrict__ out, int H,
+                                                      int tstride, int nfixed, const DecState* __restrict__ st) {
+    constexpr int NG = NT / 8;            // row groups
+    constexpr int NWV = NT / 64;
+    __shared__ float part[NWV][64];
+    __shared__ float red[2 * NWV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x;
-    const int b = bh / H, h = bh - b * H;
     const int n = st ? st->pos + 1 : nfixed;
     const int rg = tid >> 3, dc = tid & 7;
     const f16* kb = kc + (long)bh * tstride * 64 + dc * 8;
     const f16* vb = vc + (long)bh * tstride * 64 + dc * 8;
 
+    half8 kv[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) kv[i] = *reinterpret_cast<const half8*>(kb + (long)min(rg + NG * i, n - 1) * 64);
     float qv[8];
     {
-        const half8 qh = *reinterpret_cast<const half8*>(q + ((long)b * H + h) * 64 + dc * 8);
+        const half8 qh = *reinterpret_cast<const half8*>(q + (long)bh * 64 + dc * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j];
     }
-    // ---- scores
-    for (int t0 = rg; t0 < n; t0 += 128) {
-        half8 kk[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = t0 + 32 * u;
-            kk[u] = t < n ? *reinterpret_cast<const half8*>(kb + (long)t * 64) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float d = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) d += qv[j] * (float)kk[u][j];
-            d += __shfl_xor(d, 1);
-            d += __shfl_xor(d, 2);
-            d += __shfl_xor(d, 4);
-            const int t = t0 + 32 * u;
-            if (dc == 0 && t < n) sc[t] = d;
-        }
-    }
-    __syncthreads();
-    // ---- softmax over sc[0..n)
+    // ---- scores (keys past n are duplicates of key n-1 and are masked out)
+    float sv[RPT];
     float mx = -3.0e38f;
-    for (int t = tid; t < n; t += 256) mx = fmaxf(mx, sc[t]);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += qv[j] * (float)kv[i][j];
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        d += __shfl_xor(d, 4);
+        sv[i] = (rg + NG * i < n) ? d : -3.0e38f;
+        mx = fmaxf(mx, sv[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) kv[i] = *reinterpret_cast<const half8*>(vb + (long)min(rg + NG * i, n - 1) * 64);
+    // ---- softmax over all rows of the workgroup
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, red[w]);
     float sum = 0.f;
-    for (int t = tid; t < n; t += 256) {
-        const float e = __expf(sc[t] - mx);
-        sc[t] = e;
-        sum += e;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        sv[i] = __expf(sv[i] - mx);                 // masked rows: exp(-huge) = 0
+        sum += sv[i];
     }
-    sum = wave_sum(sum);
-    if (lane == 0) red[4 + wave] = sum;
-    __syncthreads();
-    sum = red[4] + red[5] + red[6] + red[7];
-    // ---- P.V
+    sum = wave_sum(sum) * 0.125f;                   // each row's score is held by its 8 lanes
+    if (lane == 0) red[NWV + wave] = sum;
+    // ---- P.V from registers
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t0 = rg; t0 < n; t0 += 128) {
-        half8 vv[4];
-        float pp[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = t0 + 32 * u;
-            const bool ok = t < n;
-            vv[u] = ok ? *reinterpret_cast<const half8*>(vb + (long)t * 64) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-            pp[u] = ok ? sc[t] : 0.f;
-        }
+    for (int i = 0; i < RPT; ++i)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += pp[u] * (float)vv[u][j];
-    }
+        for (int j = 0; j < 8; ++j) acc[j] += sv[i] * (float)kv[i][j];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float a = acc[j];
@@ -326,115 +379,172 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
     }
     __syncthreads();
     if (tid < 64) {
-        const float o = (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) / sum;
-        out[((long)b * H + h) * 64 + tid] = (f16)o;
+        float o = 0.f, s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { o += part[w][tid]; s += red[NWV + w]; }
+        out[(long)bh * 64 + tid] = (f16)(o / s);
     }
 }
 
 // ------------------------------------------------------------------ token bookkeeping
-// dec_init: position 0, first forced token embedded.  dec_finalize: choose the next token
-// (forced while inside the prompt, else the arg-max candidate), apply the end-of-text rule,
-// record it, embed it (token + learned position, modeling_whisper.py:737-762) and advance.
-// One workgroup: wave w serves sequences w, w+16.
-__global__ __launch_bounds__(1024) void dec_init_kernel(FinalizeParams p, int B, int prompt_len, int max_new, int eot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int m = wave; m < B; m += 16) {
-        const int tok = p.forced[(long)m * p.n_forced];
-        for (int c = lane; c < p.D; c += 64) p.x[(long)m * p.D + c] = (float)p.tok_emb[(long)tok * p.D + c] + (float)p.pos_emb[c];
-        for (int i = lane; i < max_new; i += 64) p.out_ids[(long)m * max_new + i] = eot;
-        if (lane == 0) { p.out_len[m] = max_new; p.finished[m] = 0; }
-    }
-    if (threadIdx.x == 0) {
+// dec_init: position 0, first forced token embedded.  dec_finalize (one workgroup per sequence):
+// choose the next token (forced while inside the prompt, else the arg-max candidate), apply the
+// end-of-text rule, record it, and embed it (token + learned position, modeling_whisper.py:737-762).
+// The position itself is advanced once per step by the final LayerNorm launch, before the logits.
+__global__ __launch_bounds__(256) void dec_init_kernel(FinalizeParams p, int B, int prompt_len, int max_new, int eot) {
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int tok = p.forced[(long)m * p.n_forced];
+    for (int c = tid; c < p.D; c += 256) p.x[(long)m * p.D + c] = (float)p.tok_emb[(long)tok * p.D + c] + (float)p.pos_emb[c];
+    for (int i = tid; i < max_new; i += 256) p.out_ids[(long)m * max_new + i] = eot;
+    if (tid == 0) { p.out_len[m] = max_new; p.finished[m] = 0; }
+    if (m == 0 && tid == 0) {
         p.st->pos = 0; p.st->prompt_len = prompt_len; p.st->max_new = max_new; p.st->eot = eot;
         p.st->n_finished = 0; p.st->batch = B;
     }
 }
 
-__global__ __launch_bounds__(1024) void dec_finalize_kernel(FinalizeParams p, int B) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pos = p.st->pos, prompt_len = p.st->prompt_len, max_new = p.st->max_new, eot = p.st->eot;
-    const int next = pos + 1;
-    for (int m = wave; m < B; m += 16) {
-        int tok;
-        if (next < prompt_len) {
-            tok = p.forced[(long)m * p.n_forced + next];
-        } else {
-            float best = -INFINITY;
-            int bidx = 0x7fffffff;
-            for (int i = lane; i < p.n_parts; i += 64) {
-                const float v = p.part_val[(long)m * p.n_parts + i];
-                const int ix = p.part_idx[(long)m * p.n_parts + i];
-                if (v > best || (v == best && ix < bidx)) { best = v; bidx = ix; }
-            }
+__global__ __launch_bounds__(256) void dec_finalize_kernel(FinalizeParams p, int B) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int next = p.st->pos, prompt_len = p.st->prompt_len, max_new = p.st->max_new, eot = p.st->eot;
+    int tok;
+    if (next < prompt_len) {
+        tok = p.forced[(long)m * p.n_forced + next];
+    } else {
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+        for (int i = tid; i < p.n_parts; i += 256) {
+            const float v = p.part_val[(long)m * p.n_parts + i];
+            const int ix = p.part_idx[(long)m * p.n_parts + i];
+            if (v > best || (v == best && ix < bidx)) { best = v; bidx = ix; }
+        }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(best, o);
-                const int oi = __shfl_xor(bidx, o);
-                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-            }
-            tok = (bidx >= 0 && bidx < p.vocab) ? bidx : eot;      // all candidates masked or NaN
-            const int sample = next - prompt_len;
-            if (p.finished[m]) {
-                tok = eot;
-            } else if (tok == eot && lane == 0 && sample < max_new) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bidx, o);
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
+        __syncthreads();
+        best = bv[0]; bidx = bi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
+        tok = (bidx >= 0 && bidx < p.vocab) ? bidx : eot;      // all candidates masked or NaN
+        const int sample = next - prompt_len;
+        const int was_finished = p.finished[m];
+        if (was_finished) tok = eot;
+        __syncthreads();                                        // every thread has read finished[m]
+        if (tid == 0 && sample < max_new) {
+            p.out_ids[(long)m * max_new + sample] = tok;
+            if (!was_finished && tok == eot) {
                 p.out_len[m] = sample;
+                p.finished[m] = 1;
                 atomicAdd(&p.st->n_finished, 1);
             }
-            const bool fin_now = tok == eot;
-            if (lane == 0 && sample < max_new) p.out_ids[(long)m * max_new + sample] = tok;
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0 && fin_now) p.finished[m] = 1;
-        }
-        if (next < p.n_text_ctx) {
-            for (int c = lane; c < p.D; c += 64)
-                p.x[(long)m * p.D + c] = (float)p.tok_emb[(long)tok * p.D + c] + (float)p.pos_emb[(long)next * p.D + c];
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) p.st->pos = next;
+    if (next < p.n_text_ctx) {
+        for (int c = tid; c < p.D; c += 256)
+            p.x[(long)m * p.D + c] = (float)p.tok_emb[(long)tok * p.D + c] + (float)p.pos_emb[(long)next * p.D + c];
+    }
+}
+
+template <int MT, int KPW, int XV>
+void launch_gemv_t(const GemvParams& p, int nw, hipStream_t s) {
+    size_t lds = (size_t)nw * MT * 64 * 16;
+    if (XV > 0) lds += (size_t)2 * p.K * 4 + (size_t)16 * MT * (p.K + 8) * 2;
+    hipLaunchKernelGGL((gemv_kernel<MT, KPW, XV>), dim3((p.N + p.nv - 1) / p.nv), dim3(nw * 64), lds, s, p);
+}
+
+constexpr int kMaxLds = 160 * 1024;
+
+template <int MT, int KPW, int XV>
+void prepare_gemv_t() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<MT, KPW, XV>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+}
+template <int MT>
+void prepare_mt() {
+    prepare_gemv_t<MT, 1, 1>(); prepare_gemv_t<MT, 2, 3>(); prepare_gemv_t<MT, 2, 4>(); prepare_gemv_t<MT, 3, 6>();
+    prepare_gemv_t<MT, 4, 8>(); prepare_gemv_t<MT, 5, 10>();
+    prepare_gemv_t<MT, 1, 0>(); prepare_gemv_t<MT, 2, 0>(); prepare_gemv_t<MT, 3, 0>(); prepare_gemv_t<MT, 4, 0>();
+    prepare_gemv_t<MT, 5, 0>(); prepare_gemv_t<MT, 6, 0>(); prepare_gemv_t<MT, 8, 0>(); prepare_gemv_t<MT, 10, 0>();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(logits_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+}
+
+template <int MT>
+bool launch_gemv_mt(const GemvParams& p, hipStream_t s) {
+    const int nks = p.K / 32;
+    if (p.ln_g) {                   // fused LayerNorm: K = d_model, 512 threads
+        switch (p.K) {
+            case 128: launch_gemv_t<MT, 1, 1>(p, 8, s); return true;
+            case 384: launch_gemv_t<MT, 2, 3>(p, 8, s); return true;
+            case 512: launch_gemv_t<MT, 2, 4>(p, 8, s); return true;
+            case 768: launch_gemv_t<MT, 3, 6>(p, 8, s); return true;
+            case 1024: launch_gemv_t<MT, 4, 8>(p, 8, s); return true;
+            case 1280: launch_gemv_t<MT, 5, 10>(p, 8, s); return true;
+            default: break;
+        }
+        // no fused instantiation for this width: separate LayerNorm launch, then the plain form
+        launch_layernorm(p.x32, p.ln_g, p.ln_b, p.ln_scratch, nullptr, p.B, p.K, s);
+        GemvParams q = p;
+        q.ln_g = nullptr; q.ln_b = nullptr; q.xin16 = p.ln_scratch;
+        return launch_gemv_mt<MT>(q, s);
+    }
+    const int nw = nks >= 48 ? 16 : nks >= 16 ? 8 : 4;
+    const int kpw = (nks + nw - 1) / nw;
+    switch (kpw) {
+        case 1: launch_gemv_t<MT, 1, 0>(p, nw, s); return true;
+        case 2: launch_gemv_t<MT, 2, 0>(p, nw, s); return true;
+        case 3: launch_gemv_t<MT, 3, 0>(p, nw, s); return true;
+        case 4: launch_gemv_t<MT, 4, 0>(p, nw, s); return true;
+        case 5: launch_gemv_t<MT, 5, 0>(p, nw, s); return true;
+        case 6: launch_gemv_t<MT, 6, 0>(p, nw, s); return true;
+        case 7: case 8: launch_gemv_t<MT, 8, 0>(p, nw, s); return true;
+        case 9: case 10: launch_gemv_t<MT, 10, 0>(p, nw, s); return true;
+        default: return false;      // K > 5120
+    }
 }
 
 }  // namespace
 
-int gemv_logits_parts(int N) { return (N + 15) / 16; }
+int gemv_logits_parts(int N) { return ((N + 15) / 16 + 7) / 8; }
 
-void launch_gemv(const GemvParams& p, hipStream_t s) {
+void dec_kernels_prepare() { prepare_mt<1>(); prepare_mt<2>(); }
+
+void launch_gemv(const GemvParams& p0, hipStream_t s) {
+    GemvParams p = p0;
     const int mt = p.B <= 16 ? 1 : 2;
     if (p.out_mode == GV_LOGITS) {
-        const int tiles = gemv_logits_parts(p.N);
-        dim3 grid((tiles + 3) / 4);
-        if (mt == 1) hipLaunchKernelGGL(logits_kernel<1>, grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(logits_kernel<2>, grid, dim3(256), 0, s, p);
+        dim3 grid(gemv_logits_parts(p.N));
+        const size_t lds = (size_t)16 * mt * (p.K + 8) * 2 + (size_t)8 * 16 * mt * 8;
+        if (mt == 1) hipLaunchKernelGGL(logits_kernel<1>, grid, dim3(512), lds, s, p);
+        else hipLaunchKernelGGL(logits_kernel<2>, grid, dim3(512), lds, s, p);
         return;
     }
     // narrow outputs: 8 rows per workgroup so that at least ~160 workgroups stream weights
-    const bool narrow = p.N <= 2048;
-    if (narrow) {
-        dim3 grid((p.N + 7) / 8);
-        if (mt == 1) hipLaunchKernelGGL((gemv_kernel<8, 1>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((gemv_kernel<8, 2>), grid, dim3(512), 0, s, p);
-    } else {
-        dim3 grid((p.N + 15) / 16);
-        if (mt == 1) hipLaunchKernelGGL((gemv_kernel<16, 1>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((gemv_kernel<16, 2>), grid, dim3(512), 0, s, p);
-    }
+    p.nv = p.N <= 2048 ? 8 : 16;
+    if (mt == 1) (void)launch_gemv_mt<1>(p, s); else (void)launch_gemv_mt<2>(p, s);
 }
 
 void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx,
                           const DecState* st, hipStream_t s) {
-    hipLaunchKernelGGL(dec_attn_kernel<448>, dim3(B * H), dim3(256), 0, s, q, kc, vc, out, H, Tctx, 0, st);
+    // 512 threads = 64 row groups x 7 rows = 448 positions
+    hipLaunchKernelGGL((dec_attn_kernel<512, 7>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st);
 }
 
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, hipStream_t s) {
-    hipLaunchKernelGGL(dec_attn_kernel<1504>, dim3(B * H), dim3(256), 0, s, q, kc, vc, out, H, T, T, (const DecState*)nullptr);
+    // 1024 threads = 128 row groups x 12 rows = 1536 >= 1500 frames
+    hipLaunchKernelGGL((dec_attn_kernel<1024, 12>), dim3(B * H), dim3(1024), 0, s, q, kc, vc, out, H, T, T, (const DecState*)nullptr);
 }
 
 void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s) {
-    hipLaunchKernelGGL(dec_init_kernel, dim3(1), dim3(1024), 0, s, p, B, prompt_len, max_new, eot);
+    hipLaunchKernelGGL(dec_init_kernel, dim3(B), dim3(256), 0, s, p, B, prompt_len, max_new, eot);
 }
 
 void launch_dec_finalize(const FinalizeParams& p, int B, hipStream_t s) {
-    hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(1024), 0, s, p, B);
+    hipLaunchKernelGGL(dec_finalize_kernel, dim3(B), dim3(256), 0, s, p, B);
 }
 
 }  // namespace mw

@@ -19,9 +19,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 constexpr int LN_MAXV = 8;     // D <= 2048
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, f16* __restrict__ y,
-                                                        float* __restrict__ y32, int rows, int D) {
+                                                        float* __restrict__ y32, int rows, int D,
+                                                        int* __restrict__ advance) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // Only the decode step passes `advance` (its position counter): no other workgroup of this launch
+    // reads it, and the launches after this one see the new value across the kernel boundary.
+    if (advance && blockIdx.x == 0 && threadIdx.x == 0) *advance += 1;
     if (row >= rows) return;
     const float* xr = x + (long)row * D;
     float4 v[LN_MAXV];
@@ -249,8 +253,9 @@ __global__ void conv_permute_kernel(const void* __restrict__ src, int dt, f16* _
 
 }  // namespace
 
-void launch_layernorm(const float* x, const float* g, const float* b, f16* y, float* y32, int rows, int D, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, y32, rows, D);
+void launch_layernorm(const float* x, const float* g, const float* b, f16* y, float* y32, int rows, int D, hipStream_t s,
+                      int* advance) {
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, y32, rows, D, advance);
 }
 
 void launch_bcast_rows(const float* table, float* x, int B, int rows, int D, hipStream_t s) {

@@ -51,7 +51,9 @@ struct GemmParams {
 void launch_gemm(const GemmParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------- encoder helpers
-void launch_layernorm(const float* x, const float* g, const float* b, f16* y, float* y32, int rows, int D, hipStream_t s);
+// `advance` (optional): an int in device memory that the launch increments by one when it is done
+void launch_layernorm(const float* x, const float* g, const float* b, f16* y, float* y32, int rows, int D, hipStream_t s,
+                      int* advance = nullptr);
 void launch_bcast_rows(const float* table, float* x, int B, int rows, int D, hipStream_t s);   // x[b][r][:] = table[r][:]
 // q,k [B][H][T][64], vT [B][H][64][Tpad] -> out [B*T][H*64] fp16
 void launch_enc_attention(const f16* q, const f16* k, const f16* vT, f16* out, int B, int H, int T, int Tpad, hipStream_t s);
@@ -78,7 +80,9 @@ struct GemvParams {
     const float* bias;        // [N] or null
     // input: LayerNorm(x32; ln_g, ln_b) when ln_g != null, else xin16
     const float* x32; const float* ln_g; const float* ln_b;
+    f16* ln_scratch;          // [B][K] fp16, used when K has no fused-LayerNorm instantiation
     const f16* xin16;
+    int nv;                   // weight rows per workgroup (8 or 16); chosen by launch_gemv
     float scale; int scale_ncols; int gelu;
     int out_mode;
     f16* out16;               // GV_F16: [B][N];  GV_QKV: q [B][D]
@@ -92,6 +96,8 @@ struct GemvParams {
 };
 void launch_gemv(const GemvParams& p, hipStream_t s);
 int gemv_logits_parts(int N);
+// raise the dynamic-LDS limit of every decode kernel instantiation once (not legal inside stream capture)
+void dec_kernels_prepare();
 
 void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx,
                           const DecState* st, hipStream_t s);
