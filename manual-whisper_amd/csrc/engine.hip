@@ -71,6 +71,7 @@ struct mw_ctx {
     uint8_t *mask_first = nullptr, *mask_rest = nullptr;
     int *forced = nullptr, *out_ids = nullptr, *out_len = nullptr, *finished = nullptr;
     int forced_cap = 0;
+    float* xpartial = nullptr; int* xtickets = nullptr;    // cross-attention key-range partials + ticket counters
 
     // decode options
     std::vector<int32_t> prompt;
@@ -226,6 +227,7 @@ static int alloc_all(mw_ctx* ctx) {
     ctx->n_parts = gemv_logits_parts(d.vocab);
     ALLOC(ctx->part_val, B * (size_t)ctx->n_parts); ALLOC(ctx->part_idx, B * (size_t)ctx->n_parts);
     ALLOC(ctx->mask_first, (size_t)d.vocab, true); ALLOC(ctx->mask_rest, (size_t)d.vocab, true);
+    ALLOC(ctx->xpartial, B * H * kXattnSplit * 68); ALLOC(ctx->xtickets, B * H, true);
     ctx->forced_cap = d.n_text_ctx;
     ALLOC(ctx->forced, B * (size_t)ctx->forced_cap);
     ALLOC(ctx->out_ids, B * (size_t)d.n_text_ctx); ALLOC(ctx->out_len, B); ALLOC(ctx->finished, B);
@@ -653,7 +655,8 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
             p.out_mode = GV_F16; p.out16 = ctx->dq;
             launch_gemv(p, s);
         }
-        launch_dec_cross_attn(ctx->dq, ctx->crossK + li * cross_layer, ctx->crossV + li * cross_layer, ctx->datt, B, H, T, s);
+        launch_dec_cross_attn(ctx->dq, ctx->crossK + li * cross_layer, ctx->crossV + li * cross_layer, ctx->datt, B, H, T,
+                              ctx->xpartial, ctx->xtickets, s);
         {   GemvParams p = base(D, D, l.co); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
         {   // LN3 + fc1 + GELU
             GemvParams p = base(F, D, l.fc1);
@@ -837,12 +840,13 @@ extern "C" int mw_profile_cross_attention(mw_ctx* ctx, int batch, int iters, flo
     const mw_model_desc& d = ctx->d;
     const size_t cross_layer = (size_t)ctx->max_batch * d.n_audio_ctx * d.d_model;
     // cycle over the layers so that successive launches read different cache regions, as in a real step
-    launch_dec_cross_attn(ctx->dq, ctx->crossK, ctx->crossV, ctx->datt, batch, d.n_heads, d.n_audio_ctx, ctx->stream);
+    launch_dec_cross_attn(ctx->dq, ctx->crossK, ctx->crossV, ctx->datt, batch, d.n_heads, d.n_audio_ctx, ctx->xpartial,
+                          ctx->xtickets, ctx->stream);
     HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
     for (int i = 0; i < iters; ++i) {
         const int li = i % d.dec_layers;
         launch_dec_cross_attn(ctx->dq, ctx->crossK + li * cross_layer, ctx->crossV + li * cross_layer, ctx->datt, batch,
-                              d.n_heads, d.n_audio_ctx, ctx->stream);
+                              d.n_heads, d.n_audio_ctx, ctx->xpartial, ctx->xtickets, ctx->stream);
     }
     HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -10,6 +10,8 @@
 // v_mfma_f32_16x16x32_f16 with the batch on the MFMA column index.
 #include "mw_kernels.h"
 
+#include <stdlib.h>
+
 namespace mw {
 
 namespace {
@@ -297,27 +299,44 @@ __global__ __launch_bounds__(512) void logits_kernel(GemvParams p) {
 }
 
 // ------------------------------------------------------------------ single-query attention over a cache
-// One workgroup per (sequence, head): scores over n keys ([n][64] fp16, contiguous), softmax, P.V.
-// Each 128-byte key/value row is fetched by 8 adjacent lanes (16 B each), 8 rows per wave
-// instruction, so every wave instruction reads 1 KiB of contiguous memory.  A thread owns RPT rows
-// (row = group + NG*i); all its K loads are issued together, and all its V loads are issued as
-// soon as the K registers are free, so V is in flight during the softmax.
+// One workgroup per (sequence, head, key range): scores over n keys ([n][64] fp16, contiguous),
+// softmax, P.V.  Each 128-byte key/value row is fetched by 8 adjacent lanes (16 B each), 8 rows per
+// wave instruction, so every wave instruction reads 1 KiB of contiguous memory.  A thread owns RPT
+// rows (row = group + NG*i); all its K loads are issued together, and all its V loads are issued
+// as soon as the K registers are free, so V is in flight during the softmax.
 // Self-attention (modeling_whisper.py:473-478): n = position + 1, every cached key is visible to the
 // newest query.  Cross-attention (:486-492): n = 1500 encoder frames, K/V cached once (:313-326).
-template <int NT, int RPT>
+//
+// S > 1 splits the keys of one (sequence, head) over S workgroups.  A CU ingests a stream at a
+// fixed rate, so a launch is only as fast as its most loaded CU: batch*heads = 320 equal workgroups
+// on 256 CUs leave 3/4 of the chip idle for half of the launch, while 1280 quarter-size ones are 5
+// per CU.  Each workgroup publishes (max, sum, unnormalised output) and takes a ticket; whoever
+// draws the last ticket merges the S partials in index order (so the result does not depend on
+// arrival order).  Hand-off between workgroups: the partial is written by ONE wave with
+// agent-scope (write-through) stores, that wave drains them (s_waitcnt vmcnt(0)) before its lane 0
+// adds to the ticket counter with an agent-scope atomic, and the last arriver's same wave reads
+// every partial back with agent-scope loads only after its own add has returned.
+constexpr int kPartStride = 68;     // floats per partial: max, sum, 64 outputs, 2 pad
+
+template <int NT, int RPT, int S>
 __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ kc,
                                                       const f16* __restrict__ vc, f16* __restrict__ out, int H,
-                                                      int tstride, int nfixed, const DecState* __restrict__ st) {
+                                                      int tstride, int nfixed, const DecState* __restrict__ st,
+                                                      float* __restrict__ partial, int* __restrict__ tickets) {
     constexpr int NG = NT / 8;            // row groups
     constexpr int NWV = NT / 64;
     __shared__ float part[NWV][64];
     __shared__ float red[2 * NWV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = blockIdx.x;
-    const int n = st ? st->pos + 1 : nfixed;
+    const int bh = S == 1 ? blockIdx.x : blockIdx.x / S;
+    const int split = S == 1 ? 0 : blockIdx.x % S;
+    const int ntot = st ? st->pos + 1 : nfixed;
+    const int per = (ntot + S - 1) / S;
+    const int t0 = split * per;
+    const int n = min(ntot, t0 + per) - t0;              // >= 1: S > 1 is only used with ntot >= S
     const int rg = tid >> 3, dc = tid & 7;
-    const f16* kb = kc + (long)bh * tstride * 64 + dc * 8;
-    const f16* vb = vc + (long)bh * tstride * 64 + dc * 8;
+    const f16* kb = kc + ((long)bh * tstride + t0) * 64 + dc * 8;
+    const f16* vb = vc + ((long)bh * tstride + t0) * 64 + dc * 8;
 
     half8 kv[RPT];
 #pragma unroll
@@ -378,11 +397,44 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
         for (int j = 0; j < 8; ++j) part[wave][lane * 8 + j] = acc[j];
     }
     __syncthreads();
-    if (tid < 64) {
-        float o = 0.f, s = 0.f;
+    if (wave != 0) return;
+    float o = 0.f, l = 0.f;
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) { o += part[w][tid]; s += red[NWV + w]; }
-        out[(long)bh * 64 + tid] = (f16)(o / s);
+    for (int w = 0; w < NWV; ++w) { o += part[w][lane]; l += red[NWV + w]; }
+    if constexpr (S == 1) {
+        out[(long)bh * 64 + lane] = (f16)(o / l);
+    } else {
+        float* mine = partial + ((long)bh * S + split) * kPartStride;
+        __hip_atomic_store(mine + 2 + lane, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            __hip_atomic_store(mine, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial has left the CU
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + bh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __shfl(ticket, 0);
+        if (ticket != S - 1) return;
+        // last arriver: every partial of this (sequence, head) is complete; merge in index order
+        float pm[S], pl[S], po[S];
+        float gm = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const float* src = partial + ((long)bh * S + i) * kPartStride;
+            pm[i] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pl[i] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            po[i] = __hip_atomic_load(src + 2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gm = fmaxf(gm, pm[i]);
+        }
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const float w = __expf(pm[i] - gm);
+            L += w * pl[i];
+            O += w * po[i];
+        }
+        out[(long)bh * 64 + lane] = (f16)(O / L);
+        if (lane == 0) __hip_atomic_store(tickets + bh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 }
 
@@ -524,19 +576,24 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
         return;
     }
     // narrow outputs: 8 rows per workgroup so that at least ~160 workgroups stream weights
-    p.nv = p.N <= 2048 ? 8 : 16;
+    static const int nv_narrow = getenv("MW_NV_NARROW") ? atoi(getenv("MW_NV_NARROW")) : 8;
+    static const int nv_wide = getenv("MW_NV_WIDE") ? atoi(getenv("MW_NV_WIDE")) : 16;
+    p.nv = p.N <= 2048 ? nv_narrow : nv_wide;
     if (mt == 1) (void)launch_gemv_mt<1>(p, s); else (void)launch_gemv_mt<2>(p, s);
 }
 
 void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx,
                           const DecState* st, hipStream_t s) {
     // 512 threads = 64 row groups x 7 rows = 448 positions
-    hipLaunchKernelGGL((dec_attn_kernel<512, 7>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st);
+    hipLaunchKernelGGL((dec_attn_kernel<512, 7, 1>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st,
+                       (float*)nullptr, (int*)nullptr);
 }
 
-void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, hipStream_t s) {
-    // 1024 threads = 128 row groups x 12 rows = 1536 >= 1500 frames
-    hipLaunchKernelGGL((dec_attn_kernel<1024, 12>), dim3(B * H), dim3(1024), 0, s, q, kc, vc, out, H, T, T, (const DecState*)nullptr);
+void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
+                           int* tickets, hipStream_t s) {
+    // 4 key ranges of 375 frames per (sequence, head); 256 threads = 32 row groups x 12 rows = 384 >= 375
+    hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, kc, vc, out, H,
+                       T, T, (const DecState*)nullptr, partial, tickets);
 }
 
 void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s) {

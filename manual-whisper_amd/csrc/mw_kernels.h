@@ -101,7 +101,12 @@ void dec_kernels_prepare();
 
 void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx,
                           const DecState* st, hipStream_t s);
-void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, hipStream_t s);
+// Cross-attention splits each (sequence, head) over kXattnSplit workgroups; `partial` holds
+// B*H*kXattnSplit*68 floats and `tickets` B*H ints that must be zero before the first launch
+// (every launch leaves them zero again).
+constexpr int kXattnSplit = 4;
+void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
+                           int* tickets, hipStream_t s);
 
 struct FinalizeParams {
     DecState* st;
