@@ -81,6 +81,13 @@ int mw_finalize(mw_ctx* ctx);
 
 int mw_set_decode_opts(mw_ctx* ctx, const mw_decode_opts* opts);
 
+/* A second engine on the same GPU that shares the (finalized) parent's weights and has its own
+ * stream, workspaces, K/V caches and decode options (copied from the parent at this moment).
+ * Parent and forks may be driven from different host threads at the same time: at batch 16 most
+ * decode launches are latency-bound, so two or three engines in flight raise throughput.
+ * Destroy every fork before its parent.  No counterpart in the reference (single engine). */
+int mw_fork(mw_ctx* parent, mw_ctx** out);
+
 /* Free everything the context owns (reference transcribe.py:153-154 `del model`). */
 void mw_destroy(mw_ctx* ctx);
 

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmwhip.so")
 
 # every symbol include/mwhip.h declares
 SYMBOLS = (
-    "mw_create", "mw_set_weight", "mw_finalize", "mw_set_decode_opts", "mw_destroy", "mw_last_error",
+    "mw_create", "mw_fork", "mw_set_weight", "mw_finalize", "mw_set_decode_opts", "mw_destroy", "mw_last_error",
     "mw_logmel", "mw_encode", "mw_decode_greedy", "mw_decode_forced", "mw_transcribe_batch",
     "mw_stage_ms", "mw_profile_cross_attention", "mw_set_option", "mw_synchronize",
 )
@@ -66,6 +66,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p
     lib.mw_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.c_int, C.POINTER(vp)]
+    lib.mw_fork.argtypes = [vp, C.POINTER(vp)]
     lib.mw_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int, C.c_int]
     lib.mw_finalize.argtypes = [vp]
     lib.mw_set_decode_opts.argtypes = [vp, C.POINTER(DecodeOpts)]

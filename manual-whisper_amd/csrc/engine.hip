@@ -31,6 +31,7 @@ struct mw_ctx {
     std::vector<void*> allocs;
     bool finalized = false;
     int use_graph = 1, check_every = 16;
+    const mw_ctx* parent = nullptr;                       // non-null: weights and tables belong to `parent`
 
     // weights
     f16* conv1_w = nullptr; float* conv1_b = nullptr;     // [D][3][n_mels]
@@ -173,12 +174,9 @@ static int build_mel_tables(mw_ctx* ctx) {
     return MW_OK;
 }
 
-static int alloc_all(mw_ctx* ctx) {
+static int alloc_weights(mw_ctx* ctx) {
     const mw_model_desc& d = ctx->d;
-    const size_t D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, B = ctx->max_batch;
-    const size_t M = B * T;
-    ctx->Tpad = (int)((T + 7) / 8 * 8);
-    // weights
+    const size_t D = d.d_model, F = d.ffn_dim, T = d.n_audio_ctx;
     ALLOC(ctx->conv1_w, D * 3 * d.n_mels); ALLOC(ctx->conv1_b, D);
     ALLOC(ctx->conv2_w, D * 3 * D); ALLOC(ctx->conv2_b, D);
     ALLOC(ctx->enc_pos, T * D);
@@ -205,6 +203,15 @@ static int alloc_all(mw_ctx* ctx) {
     }
     ALLOC(ctx->dec_ln.g, D); ALLOC(ctx->dec_ln.b, D);
     ALLOC(ctx->ckv_w, (size_t)d.dec_layers * 2 * D * D); ALLOC(ctx->ckv_b, (size_t)d.dec_layers * 2 * D, true);
+    return MW_OK;
+}
+
+// Everything one stream of work needs besides the weights: workspaces, K/V caches, decode state.
+static int alloc_work(mw_ctx* ctx) {
+    const mw_model_desc& d = ctx->d;
+    const size_t D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, B = ctx->max_batch;
+    const size_t M = B * T;
+    ctx->Tpad = (int)((T + 7) / 8 * 8);
     // encoder workspaces
     ALLOC(ctx->pcm_dev, B * (size_t)kChunkSamples);
     ALLOC(ctx->logmel, B * (size_t)d.n_mels * kFrames);
@@ -255,7 +262,9 @@ extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, m
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(MW_ERR_HIP); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(MW_ERR_HIP); }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(MW_ERR_HIP); }
-    int r = alloc_all(ctx);
+    int r = alloc_weights(ctx);
+    if (r) return bail(r);
+    r = alloc_work(ctx);
     if (r) return bail(r);
     r = build_mel_tables(ctx);
     if (r) return bail(r);
@@ -276,6 +285,36 @@ extern "C" void mw_destroy(mw_ctx* ctx) {
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+extern "C" int mw_fork(mw_ctx* parent, mw_ctx** out) {
+    if (!parent || !out) return MW_ERR_ARG;
+    *out = nullptr;
+    if (!parent->finalized) return fail(parent, MW_ERR_STATE, "mw_fork: the parent must be finalized first");
+    if (parent->parent) return fail(parent, MW_ERR_ARG, "mw_fork: fork from the original engine, not from a fork");
+    mw_ctx* ctx = new mw_ctx();
+    ctx->d = parent->d; ctx->device = parent->device; ctx->max_batch = parent->max_batch;
+    ctx->use_graph = parent->use_graph; ctx->check_every = parent->check_every;
+    ctx->parent = parent; ctx->finalized = true;
+    // shared, read-only on the hot path
+    ctx->conv1_w = parent->conv1_w; ctx->conv1_b = parent->conv1_b; ctx->conv2_w = parent->conv2_w; ctx->conv2_b = parent->conv2_b;
+    ctx->enc_pos = parent->enc_pos; ctx->enc = parent->enc; ctx->enc_ln = parent->enc_ln;
+    ctx->tok_emb = parent->tok_emb; ctx->dec_pos = parent->dec_pos; ctx->dec = parent->dec; ctx->dec_ln = parent->dec_ln;
+    ctx->ckv_w = parent->ckv_w; ctx->ckv_b = parent->ckv_b;
+    ctx->basis_cos = parent->basis_cos; ctx->basis_sin = parent->basis_sin; ctx->filt = parent->filt; ctx->n_mels_pad = parent->n_mels_pad;
+    ctx->prompt = parent->prompt; ctx->eot = parent->eot; ctx->max_new = parent->max_new; ctx->opts_set = parent->opts_set;
+    auto bail = [&](int code) { parent->err = "mw_fork: " + ctx->err; mw_destroy(ctx); return code; };
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(MW_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(MW_ERR_HIP); }
+    for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(MW_ERR_HIP); }
+    int r = alloc_work(ctx);
+    if (r) return bail(r);
+    const size_t V = ctx->d.vocab;
+    if (hipMemcpyAsync(ctx->mask_first, parent->mask_first, V, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(ctx->mask_rest, parent->mask_rest, V, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "copying the suppress masks failed"; return bail(MW_ERR_HIP); }
+    *out = ctx;
+    return MW_OK;
 }
 
 extern "C" const char* mw_last_error(const mw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -376,6 +415,7 @@ static bool resolve(mw_ctx* ctx, const std::string& name, Slot* s, std::vector<i
 
 extern "C" int mw_set_weight(mw_ctx* ctx, const char* name_c, const void* data, const int64_t* shape, int ndim, int dtype) {
     if (!ctx) return MW_ERR_ARG;
+    if (ctx->parent) return fail(ctx, MW_ERR_STATE, "mw_set_weight: a fork shares its parent's weights");
     if (!name_c || !data || !shape || ndim < 1 || ndim > 3) return fail(ctx, MW_ERR_ARG, "mw_set_weight: null or bad argument");
     if (dtype < MW_F32 || dtype > MW_BF16) return fail(ctx, MW_ERR_ARG, "mw_set_weight: dtype must be MW_F32, MW_F16 or MW_BF16");
     const std::string name(name_c);
@@ -412,6 +452,7 @@ extern "C" int mw_set_weight(mw_ctx* ctx, const char* name_c, const void* data, 
 
 extern "C" int mw_finalize(mw_ctx* ctx) {
     if (!ctx) return MW_ERR_ARG;
+    if (ctx->parent) return MW_OK;
     const mw_model_desc& d = ctx->d;
     std::vector<std::string> need = {"model.encoder.conv1.weight", "model.encoder.conv1.bias", "model.encoder.conv2.weight",
                                      "model.encoder.conv2.bias", "model.encoder.layer_norm.weight", "model.encoder.layer_norm.bias",

@@ -6,6 +6,7 @@ compute happens inside libmwhip.so.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Mapping, Optional, Sequence
 
 import numpy as np
@@ -44,6 +45,21 @@ class Engine:
         if rc != 0:
             raise EngineError(f"mw_create failed ({rc}): {self._lib.mw_last_error(None).decode()}")
         self._h = h
+        self._forks = []
+
+    def fork(self) -> "Engine":
+        """A second engine on the same GPU sharing these weights (own stream and caches); safe to
+        drive from another thread while this one is busy."""
+        h = C.c_void_p()
+        self._check(self._lib.mw_fork(self._h, C.byref(h)), "mw_fork")
+        child = object.__new__(Engine)
+        child._lib, child.dims, child.device, child.max_batch = self._lib, self.dims, self.device, self.max_batch
+        child.opts = self.opts
+        child._h = h
+        child._parent = self          # keeps the weights alive
+        child._forks = []
+        self._forks.append(weakref.ref(child))
+        return child
 
     # -- plumbing -------------------------------------------------------------
     def _check(self, rc: int, what: str):
@@ -51,6 +67,10 @@ class Engine:
             raise EngineError(f"{what} failed ({rc}): {self._lib.mw_last_error(self._h).decode()}")
 
     def close(self):
+        for ref in getattr(self, "_forks", []):      # forks borrow this engine's weights: they go first
+            child = ref()
+            if child is not None:
+                child.close()
         if getattr(self, "_h", None):
             self._lib.mw_destroy(self._h)
             self._h = None

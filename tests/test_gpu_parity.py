@@ -250,3 +250,24 @@ def test_weight_dtypes_equivalent(micro):
     ids, _ = e3.transcribe_batch(torch.from_numpy(pcm).cuda())    # device-resident audio
     e3.close()
     assert (ids == ref_ids).all()
+
+
+def test_forks_share_weights_and_run_concurrently(micro):
+    """Forked engines (own stream/caches, shared weights) driven from threads give the same ids as
+    the parent run alone, in the submitted order."""
+    from manual_whisper_amd.scheduler import EnginePool
+    dims, w, eng = micro
+    opts = synthetic_options(dims, max_new=8)
+    eng.set_decode_options(opts)
+    batches = [synth.make_pcm_np(4, seed=60 + i) for i in range(7)]
+    want = [eng.transcribe_batch(b) for b in batches]
+    pool = EnginePool(eng, 3)
+    try:
+        for _ in range(2):
+            got = pool.map(batches)
+            for (gi, gl), (wi, wl) in zip(got, want):
+                assert (gi == wi).all() and (gl == wl).all()
+    finally:
+        pool._pool.shutdown(wait=True)
+        for e in pool.engines[1:]:
+            e.close()
