@@ -1,0 +1,109 @@
+"""Command line front end: same arguments, files and prints as reference transcribe.py:229-251.
+
+    python transcribe.py <audio>        ->  <stem>_transcript.md + <stem>_transcript.json in the CWD
+
+Environment (reference transcribe.py:30-36 plus this engine's own knobs):
+  BATCH_SIZE     chunks per engine call (default 16 here; the reference's CPU default is 4)
+  WHISPER_MODEL  model size / local checkpoint directory / synthetic:<size> (default large-v3)
+  MW_MODEL_DIR   where model-size names are looked up
+  MW_ENGINES     engines in flight on the GPU (default 2)
+  HF_TOKEN       accepted for compatibility; diarization is not part of this engine
+Launched under torch.distributed.run, the chunks are sharded over the ranks and rank 0 writes the files.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from pathlib import Path
+
+from . import emit, postprocess
+from .audio import load_audio
+from .dims import SAMPLE_RATE
+from .model import load_model
+
+DEVICE = os.environ.get("MW_DEVICE", "cuda")
+BATCH_SIZE = int(os.environ.get("BATCH_SIZE", "16"))
+COMPUTE_TYPE = os.environ.get("MW_DTYPE", "float16")
+MODEL_SIZE = os.environ.get("WHISPER_MODEL", "large-v3")
+HF_TOKEN = os.environ.get("HF_TOKEN")
+
+# reference transcribe.py:39-46
+DOMAIN_TERMS = ["微信", "支付宝", "二维码", "收款码", "小程序", "公众号", "NFC", "Node ID", "UID", "UIA", "ADNA", "APP", "H5"]
+INITIAL_PROMPT = f"中文会议讨论记录，保持原意与术语准确。术语参考：{'、'.join(DOMAIN_TERMS)}。"
+VAD_OPTIONS = {"vad_onset": 0.5, "vad_offset": 0.363}
+
+
+def _dist_env():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world
+
+
+def transcribe_audio(audio_file, hf_token=None):
+    """Load, transcribe, clean.  Returns (result dict, audio duration in seconds)."""
+    rank, local_rank, world = _dist_env()
+    say = print if rank == 0 else (lambda *a, **k: None)
+    say(f"🎙️ 正在转写: {audio_file}")
+    say(f"📊 配置: 模型={MODEL_SIZE} | 设备={DEVICE} | 精度={COMPUTE_TYPE} | 批大小={BATCH_SIZE}")
+    t = time.time()
+    say(f"📝 加载 Whisper {MODEL_SIZE} 模型...")
+    model = load_model(MODEL_SIZE, DEVICE, device_index=local_rank, compute_type=COMPUTE_TYPE, language="zh",
+                       asr_options={"initial_prompt": INITIAL_PROMPT}, vad_options=VAD_OPTIONS,
+                       max_batch=min(32, max(1, BATCH_SIZE)), n_engines=int(os.environ.get("MW_ENGINES", "2")))
+    say(f"   模型加载耗时: {time.time() - t:.1f}s")
+    say("🔊 加载音频...")
+    audio = load_audio(audio_file)
+    audio_duration = len(audio) / SAMPLE_RATE
+    say(f"   音频时长: {audio_duration:.0f}s ({audio_duration/60:.1f}min)")
+    t = time.time()
+    say("✍️ 转写中 (可能需要几分钟)...")
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from .parallel import transcribe_sharded
+        from .scheduler import split_chunks
+        if not dist.is_initialized():
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        chunks, spans = split_chunks(audio)
+        ids = transcribe_sharded(lambda c: model.transcribe_ids_chunks(c, BATCH_SIZE, "zh"), chunks, model.max_new,
+                                 device=torch.device("cuda", local_rank))
+        result = {"segments": [{"text": model.detokenize(i), "start": round(a, 3), "end": round(b, 3)}
+                               for (a, b), i in zip(spans, ids)], "language": "zh"}
+    else:
+        result = model.transcribe(audio, batch_size=BATCH_SIZE, language="zh")
+        for seg in result["segments"]:
+            seg.pop("tokens", None)
+    dt = time.time() - t
+    say(f"   转写耗时: {dt:.1f}s (实时比: {dt/max(audio_duration, 1e-9):.3f}x, {audio_duration/max(dt, 1e-9):.0f} audio-s/s)")
+    say("⚠️ 时间戳对齐与说话人分离不在本引擎范围内：片段时间为 30 秒分块边界。")
+    model.close()
+    say("🧹 清理转写文本...")
+    kept, changed, dropped = postprocess.clean_segments(result.get("segments", []))
+    result["segments"] = kept
+    if changed:
+        say(f"   修复了 {changed} 处文本问题")
+    if dropped:
+        say(f"   删除了 {dropped} 条提示词污染片段")
+    return result, audio_duration
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    t0 = time.time()
+    audio_file = argv[1] if len(argv) > 1 else "New Recording 46.m4a"
+    if not os.path.exists(audio_file):
+        print(f"❌ 文件不存在: {audio_file}")
+        sys.exit(1)
+    output_file = Path(audio_file).stem + "_transcript.md"
+    result, audio_duration = transcribe_audio(audio_file, HF_TOKEN)
+    total = time.time() - t0
+    if _dist_env()[0] == 0:
+        emit.format_transcript(result, audio_file, output_file, audio_duration, total, model_size=MODEL_SIZE,
+                               compute_type=COMPUTE_TYPE, device=DEVICE)
+        print("\n🎉 转写完成!")
+        print(f"⏱️ 总耗时: {total:.1f}s | 音频时长: {audio_duration:.0f}s | 实时比: {total/max(audio_duration, 1e-9):.3f}x")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+"""``load_model`` / ``Model.transcribe``: the call surface of reference transcribe.py:107-123.
+
+    model = load_model(MODEL_SIZE, DEVICE, compute_type=..., language="zh",
+                       asr_options={"initial_prompt": ...}, vad_options=...)
+    result = model.transcribe(audio, batch_size=BATCH_SIZE, language="zh")
+    # {"segments": [{"text", "start", "end"}, ...], "language": "zh"}
+
+Differences that cannot be avoided offline, all stated where they bite:
+  * weights come from a LOCAL directory in Hugging Face layout (config.json + model.safetensors or
+    pytorch_model.bin [+ tokenizer.json]); nothing is downloaded.  ``synthetic:<size>`` builds the
+    deterministic random-init checkpoint used by the tests and the benchmark.
+  * windows are fixed 30 s chunks; ``vad_options`` is accepted and recorded but no VAD model runs.
+  * decoding is greedy without timestamps; text needs tokenizer.json, otherwise a segment's text is
+    its token ids written as ``<|id|>`` and the ids are also returned under ``"tokens"``.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Optional
+
+import numpy as np
+
+from .decode_options import DecodeOptions, synthetic_options, whisper_options
+from .dims import MODELS, WhisperDims, get_dims
+from .engine import Engine, EngineError
+from .scheduler import EnginePool, batches_of, split_chunks
+
+_GPU_NAMES = ("cuda", "hip", "gpu", "rocm")
+_FP16_NAMES = ("float16", "fp16", "half", "default")
+
+
+def _dims_from_config(path: str) -> WhisperDims:
+    with open(os.path.join(path, "config.json"), encoding="utf-8") as f:
+        c = json.load(f)
+    return WhisperDims(os.path.basename(os.path.normpath(path)), c["num_mel_bins"], c["d_model"],
+                       c["encoder_attention_heads"], c["encoder_layers"], c["decoder_layers"],
+                       c["encoder_ffn_dim"], c["vocab_size"], c.get("max_source_positions", 1500),
+                       c.get("max_target_positions", 448))
+
+
+def _load_state_dict(path: str) -> dict:
+    """Tensors only: safetensors, or a torch checkpoint opened with weights_only=True."""
+    st = os.path.join(path, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.numpy import load_file
+        return load_file(st)
+    pt = os.path.join(path, "pytorch_model.bin")
+    if os.path.exists(pt):
+        import torch
+        return torch.load(pt, map_location="cpu", weights_only=True)
+    raise FileNotFoundError(f"{path}: no model.safetensors or pytorch_model.bin")
+
+
+class Model:
+    def __init__(self, engine: Engine, dims: WhisperDims, language: str, tokenizer=None,
+                 initial_prompt: Optional[str] = None, vad_options: Optional[dict] = None,
+                 synthetic: bool = False, max_new: int = 224, n_engines: int = 1):
+        self.engine, self.dims, self.language = engine, dims, language
+        self.tokenizer, self.initial_prompt = tokenizer, initial_prompt
+        self.vad_options = dict(vad_options or {})
+        self.synthetic, self.max_new = synthetic, max_new
+        self.pool = EnginePool(engine, n_engines)
+        self._opts_for = None
+
+    # -- decoding rules ---------------------------------------------------------------
+    def decode_options(self, language: str) -> DecodeOptions:
+        if self.synthetic and self.dims.vocab < 51865:
+            return synthetic_options(self.dims, max_new=min(self.max_new, 64))
+        prompt_ids = ()
+        if self.initial_prompt and self.tokenizer is not None:
+            prompt_ids = tuple(self.tokenizer.encode(" " + self.initial_prompt.strip(), add_special_tokens=False).ids)
+        elif self.initial_prompt:
+            print("⚠️ initial_prompt ignored: no tokenizer.json next to the weights")
+        return whisper_options(self.dims, language, prompt_ids, max_new=self.max_new)
+
+    def detokenize(self, ids) -> str:
+        ids = [int(i) for i in ids]
+        if self.tokenizer is not None:
+            return self.tokenizer.decode(ids, skip_special_tokens=True)
+        return "".join(f"<|{i}|>" for i in ids)
+
+    # -- the hot path -------------------------------------------------------------------
+    def transcribe_ids(self, audio: np.ndarray, batch_size: int = 16, language: Optional[str] = None):
+        """-> (chunk spans [(start, end)], list of id arrays), no text handling."""
+        language = language or self.language
+        if self._opts_for != language:
+            self.pool.set_decode_options(self.decode_options(language))
+            self._opts_for = language
+        chunks, spans = split_chunks(audio)
+        return spans, self.transcribe_ids_chunks(chunks, batch_size, language)
+
+    def transcribe_ids_chunks(self, chunks: np.ndarray, batch_size: int = 16, language: Optional[str] = None):
+        """Already-cut chunks [n, 480000] -> list of id arrays (used by the multi-rank path)."""
+        language = language or self.language
+        if self._opts_for != language:
+            self.pool.set_decode_options(self.decode_options(language))
+            self._opts_for = language
+        bs = max(1, min(int(batch_size), self.engine.max_batch))
+        out = []
+        for ids, lens in self.pool.map([chunks[a:b] for a, b in batches_of(len(chunks), bs)]):
+            out.extend(ids[i, : lens[i]].copy() for i in range(ids.shape[0]))
+        return out
+
+    def transcribe(self, audio: np.ndarray, batch_size: int = 16, language: Optional[str] = None, **_ignored) -> dict:
+        language = language or self.language
+        spans, ids = self.transcribe_ids(audio, batch_size, language)
+        segments = [{"text": self.detokenize(t), "start": round(a, 3), "end": round(b, 3), "tokens": [int(i) for i in t]}
+                    for (a, b), t in zip(spans, ids)]
+        return {"segments": segments, "language": language}
+
+    def close(self):
+        self.pool.close()
+
+
+def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, compute_type: str = "float16",
+               asr_options: Optional[dict] = None, language: Optional[str] = None, vad_options: Optional[dict] = None,
+               task: str = "transcribe", max_batch: int = 16, n_engines: int = 1, **_ignored) -> Model:
+    """Build an engine on GPU ``device_index``.
+
+    whisper_arch: a local directory in Hugging Face layout, a model size whose directory is
+    ``$MW_MODEL_DIR/<size>``, or ``synthetic:<size>``.
+    """
+    if device not in _GPU_NAMES:
+        raise EngineError(f"device={device!r}: this engine runs on an MI355X GPU only (use 'cuda'); there is no CPU path")
+    if compute_type not in _FP16_NAMES:
+        raise EngineError(f"compute_type={compute_type!r} is not available: weights are fp16 with fp32 accumulation ('float16')")
+    if task != "transcribe":
+        raise EngineError("only task='transcribe' is implemented")
+    asr_options = dict(asr_options or {})
+    synthetic = whisper_arch.startswith("synthetic:")
+    tokenizer = None
+    if synthetic:
+        from . import synth
+        dims = get_dims(whisper_arch.split(":", 1)[1])
+        try:
+            import torch
+            weights = synth.make_weights_torch(dims, 1234, torch.device("cuda", device_index))
+        except Exception:
+            weights = synth.make_weights_np(dims, 1234)
+    else:
+        path = whisper_arch
+        if not os.path.isdir(path):
+            root = os.environ.get("MW_MODEL_DIR")
+            cand = os.path.join(root, whisper_arch) if root else None
+            if cand and os.path.isdir(cand):
+                path = cand
+            else:
+                raise FileNotFoundError(
+                    f"model {whisper_arch!r}: not a directory, and no $MW_MODEL_DIR/{whisper_arch}. Nothing is downloaded: "
+                    "point to a local Hugging Face-layout checkpoint (known sizes: " + ", ".join(sorted(MODELS)) + ")")
+        dims = _dims_from_config(path)
+        weights = _load_state_dict(path)
+        tok = os.path.join(path, "tokenizer.json")
+        if os.path.exists(tok):
+            from tokenizers import Tokenizer
+            tokenizer = Tokenizer.from_file(tok)
+    engine = Engine(dims, device=device_index, max_batch=max_batch)
+    engine.load_weights(weights)
+    del weights
+    return Model(engine, dims, language or "zh", tokenizer, asr_options.get("initial_prompt"), vad_options,
+                 synthetic=synthetic, max_new=int(asr_options.get("max_new_tokens", 224)), n_engines=n_engines)

@@ -271,3 +271,32 @@ def test_forks_share_weights_and_run_concurrently(micro):
         pool._pool.shutdown(wait=True)
         for e in pool.engines[1:]:
             e.close()
+
+
+def test_cli_end_to_end(tmp_path):
+    """`python transcribe.py x.wav` with a synthetic checkpoint: files appear, segments are the 30 s
+    chunk spans, and ids equal Model.transcribe_ids on the same audio."""
+    import json
+    import subprocess
+    import sys
+    from manual_whisper_amd import audio as aud
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    x = synth.make_pcm_np(3, seed=71).reshape(-1)[: 16000 * 70]          # 70 s -> 3 chunks, last one padded
+    wav = tmp_path / "meeting.wav"
+    aud.write_wav(str(wav), x)
+    env = dict(os.environ, WHISPER_MODEL="synthetic:micro", BATCH_SIZE="2", MW_ENGINES="2")
+    r = subprocess.run([sys.executable, os.path.join(root, "transcribe.py"), str(wav)], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    md = (tmp_path / "meeting_transcript.md").read_text(encoding="utf-8")
+    js = json.loads((tmp_path / "meeting_transcript.json").read_text(encoding="utf-8"))
+    assert md.startswith("# 会议录音转写") and "[00:00:00 - 00:00:30]" in md and "[00:01:00 - 00:01:10]" in md
+    assert [s["start"] for s in js["segments"]] == [0.0, 30.0, 60.0] and js["segments"][2]["end"] == 70.0
+    model = mw.load_model("synthetic:micro", "cuda", max_batch=2, n_engines=1)
+    spans, ids = model.transcribe_ids(mw.load_audio(str(wav)), batch_size=2)
+    model.close()
+    for seg, t in zip(js["segments"], ids):
+        assert seg["text"] == "".join(f"<|{i}|>" for i in t)
+    missing = subprocess.run([sys.executable, os.path.join(root, "transcribe.py"), "nope.wav"], cwd=tmp_path, env=env,
+                             capture_output=True, text=True, timeout=120)
+    assert missing.returncode == 1 and "文件不存在" in missing.stdout

@@ -1,0 +1,105 @@
+"""Host logic that needs no GPU: audio decoding, chunk scheduling, the multi-rank exchange (gloo,
+world size 2), and that the C-ABI library loads and exports every declared symbol."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import manual_whisper_amd as mw
+from manual_whisper_amd import audio, parallel, scheduler
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_wav_roundtrip_and_resample(tmp_path):
+    t = np.arange(16000) / 16000.0
+    x = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    p = tmp_path / "a.wav"
+    audio.write_wav(str(p), x)
+    y = mw.load_audio(str(p))
+    assert y.dtype == np.float32 and y.shape == x.shape and np.abs(y - x).max() < 1e-4
+    p8 = tmp_path / "b.wav"
+    audio.write_wav(str(p8), x[::2], rate=8000)               # 8 kHz -> 16 kHz
+    z = mw.load_audio(str(p8))
+    assert abs(len(z) - 16000) <= 2 and np.abs(z[200:-200] - x[200:len(z) - 200]).max() < 0.05
+    with pytest.raises((RuntimeError, ValueError)):
+        q = tmp_path / "c.m4a"
+        q.write_bytes(b"not audio at all")
+        mw.load_audio(str(q))
+
+
+def test_split_chunks_edges():
+    c, s = scheduler.split_chunks(np.zeros(0, np.float32))
+    assert c.shape == (0, 480000) and s == []
+    c, s = scheduler.split_chunks(np.ones(480000, np.float32))
+    assert c.shape == (1, 480000) and s == [(0.0, 30.0)]
+    c, s = scheduler.split_chunks(np.ones(480001, np.float32))
+    assert c.shape == (2, 480000) and c[1, 0] == 1 and (c[1, 1:] == 0).all() and s[1] == (30.0, 480001 / 16000)
+    assert scheduler.batches_of(5, 2) == [(0, 2), (2, 4), (4, 5)] and scheduler.batches_of(0, 4) == []
+
+
+def test_shard_and_pack():
+    for n in (0, 1, 7, 120):
+        for w in (1, 2, 8):
+            r = [parallel.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    ids = [np.array([3, 4, 5]), np.array([], np.int32), np.array([9])]
+    rows = parallel.pack_rows(ids, 4, 5)
+    assert rows.shape == (5, 5) and rows[3, 0] == -1
+    back = parallel.unpack_rows(rows)
+    assert len(back) == 3 and all((a == b).all() for a, b in zip(back, ids))
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch.distributed as dist
+import manual_whisper_amd
+from manual_whisper_amd import parallel
+dist.init_process_group("gloo")
+n = int(sys.argv[1])
+chunks = np.arange(n, dtype=np.float32)[:, None] * np.ones((1, 8), np.float32)
+def fake(c):      # ids derived from the chunk's content; ragged lengths incl. empty
+    return [np.arange(int(v[0]) %% 4, dtype=np.int32) + int(v[0]) * 10 for v in c]
+out = parallel.transcribe_sharded(fake, chunks, max_new=5)
+want = fake(chunks)
+assert len(out) == n and all((a == b).all() for a, b in zip(out, want)), (out, want)
+print("rank", dist.get_rank(), "ok")
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("n_chunks", [0, 1, 5, 8])
+def test_sharded_gather_world2_gloo(tmp_path, n_chunks):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29500 + n_chunks + os.getpid() % 200),
+                        str(script), str(n_chunks)], capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
+
+
+def test_library_exports_every_declared_symbol():
+    from manual_whisper_amd import _lib
+    header = open(os.path.join(ROOT, "include", "mwhip.h")).read()
+    declared = set(re.findall(r"\b(mw_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_load_model_rejects_what_it_cannot_do():
+    from manual_whisper_amd.engine import EngineError
+    with pytest.raises(EngineError, match="GPU only"):
+        mw.load_model("synthetic:micro", "cpu")
+    with pytest.raises(EngineError, match="compute_type"):
+        mw.load_model("synthetic:micro", "cuda", compute_type="int8")
+    with pytest.raises(FileNotFoundError, match="Nothing is downloaded"):
+        mw.load_model("large-v3", "cuda")
