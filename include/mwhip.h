@@ -123,13 +123,13 @@ int mw_transcribe_batch(mw_ctx* ctx, const float* pcm, int batch, int32_t* out_i
 /* ---- measurement ---- */
 
 /* GPU time in ms of the last call's stages, from HIP events on the context's stream:
- * [0] log-mel  [1] encoder  [2] cross K/V  [3] decode loop  [4] number of decode steps
- * [5] mean duration of the cross-attention decode kernel over the loop's steps is NOT here:
- * see mw_profile_cross_attention. */
+ * [0] log-mel  [1] encoder  [2] cross K/V  [3] decode loop  [4] number of decode steps run.
+ * (The reference prints time.time() deltas per stage: transcribe.py:114,124-125.) */
 int mw_stage_ms(mw_ctx* ctx, float out[5]);
 
-/* Re-run only the decode-time cross-attention kernel of layer 0 `iters` times on the
- * current caches and report its mean duration (ms) and the bytes it must read per launch. */
+/* Re-run only the decode-time cross-attention kernel `iters` times back to back on the current
+ * caches (cycling through the layers) and report its mean duration (ms, HIP events on the
+ * context's stream) and the K/V bytes one launch must read. */
 int mw_profile_cross_attention(mw_ctx* ctx, int batch, int iters, float* mean_ms, double* bytes_per_launch);
 
 /* Engine options: key "graph" (1 = capture the decode step into a hipGraph, default 1),
