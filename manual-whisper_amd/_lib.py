@@ -44,6 +44,8 @@ def _share_torch_hip_runtime():
     finds the very same file already mapped.  Without torch the system ROCm runtime is used.
     """
     import importlib.util
+    if os.environ.get("MW_SYSTEM_HIP") == "1":     # torch-free process (e.g. under a counter profiler): system runtime
+        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):

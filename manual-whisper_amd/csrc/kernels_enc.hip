@@ -89,8 +89,16 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16* __restric
     __shared__ __attribute__((aligned(16))) f16 lds[2][2][AKV * 64];     // [buffer][K | V^T][64 x 64] = 32 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int bh = blockIdx.y;
-    const int q0 = blockIdx.x * AQ + wave * 32;
+    // 1-D grid, XCD-aware: blocks b and b+8 share an XCD, so give each XCD a contiguous run of
+    // (head, query-tile) pairs; the query tiles of one head then read its K/V through one L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+    }
+    const int nqt = (T + AQ - 1) / AQ;
+    const int bh = bid / nqt;
+    const int q0 = (bid - bh * nqt) * AQ + wave * 32;
     const f16* qb = q + (long)bh * T * 64;
     const f16* kb = k + (long)bh * T * 64;
     const f16* vb = vT + (long)bh * 64 * Tpad;
@@ -264,7 +272,7 @@ void launch_bcast_rows(const float* table, float* x, int B, int rows, int D, hip
 }
 
 void launch_enc_attention(const f16* q, const f16* k, const f16* vT, f16* out, int B, int H, int T, int Tpad, hipStream_t s) {
-    hipLaunchKernelGGL(enc_attention_kernel, dim3((T + AQ - 1) / AQ, B * H), dim3(256), 0, s, q, k, vT, out, H, T, Tpad);
+    hipLaunchKernelGGL(enc_attention_kernel, dim3(((T + AQ - 1) / AQ) * B * H), dim3(256), 0, s, q, k, vT, out, H, T, Tpad);
 }
 
 void launch_convert(const void* src, int src_dtype, void* dst, int dst_is_f16, long n, hipStream_t s) {

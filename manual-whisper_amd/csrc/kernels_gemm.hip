@@ -33,16 +33,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
-    // contiguous run of tiles so neighbours that share an A row-panel hit the same L2.
+    // Tile order.  (1) XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch), so each XCD
+    // gets a contiguous run of tile ids.  (2) Inside a run, ids walk GROUP_M row-tiles for one
+    // column-tile before moving to the next column-tile, so the ~64 tiles an XCD runs at once form
+    // an 8 x 8 patch that shares 8 A panels and 8 W panels in its 4 MiB L2 (a row-major walk
+    // re-streams all of W from the Infinity Cache for every row-tile).
     const int nt_n = (p.N + BN - 1) / BN;
+    const int nt_m = (p.M + BM - 1) / BM;
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (bid / nt_n) * BM, n0 = (bid % nt_n) * BN;
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * nt_n;
+    const int group = bid / per_group;
+    const int gm0 = group * GROUP_M;
+    const int gsz = min(GROUP_M, nt_m - gm0);
+    const int in_group = bid - group * per_group;
+    const int m0 = (gm0 + in_group % gsz) * BM, n0 = (in_group / gsz) * BN;
 
     // staging: 4 chunks of 16 B per thread per operand; chunk id = tid + 256*i -> row = id>>3, col chunk = id&7
     const f16* a_ptr[4];

@@ -78,41 +78,48 @@ def tensor_specs(d: WhisperDims):
         yield prefix + ".weight", (D,), "gamma", 0.2
         yield prefix + ".bias", (D,), "vec", 0.1
 
-    def attn(prefix):
-        yield from lin(prefix + ".q_proj", D, D)
-        yield from lin(prefix + ".k_proj", D, D, bias=False)
+    def attn(prefix, res_gain):
+        # q/k gain 2: attention logits of std ~4, peaked enough that outputs depend on WHICH frames
+        # or tokens are attended (near-uniform attention makes every chunk decode to the same ids)
+        yield from lin(prefix + ".q_proj", D, D, gain=2.0)
+        yield from lin(prefix + ".k_proj", D, D, bias=False, gain=2.0)
         yield from lin(prefix + ".v_proj", D, D)
-        yield from lin(prefix + ".out_proj", D, D)
+        yield from lin(prefix + ".out_proj", D, D, gain=res_gain)
 
+    # Branch outputs shrink with depth (as in GPT-2 style initialisation): otherwise the residual
+    # stream of a 32-layer model is a sum of ~100 nearly input-independent vectors and every chunk
+    # decodes to the same ids.
+    enc_res = 0.8 * min(1.0, math.sqrt(4.0 / (2 * d.enc_layers)))
+    dec_res = 0.8 * min(1.0, math.sqrt(4.0 / (3 * d.dec_layers)))
     e = "model.encoder"
-    yield e + ".conv1.weight", (D, d.n_mels, 3), "mat", 0.8 * sq3 / math.sqrt(3 * d.n_mels)
+    yield e + ".conv1.weight", (D, d.n_mels, 3), "mat", 2.0 * sq3 / math.sqrt(3 * d.n_mels)
     yield e + ".conv1.bias", (D,), "vec", 0.1
-    yield e + ".conv2.weight", (D, D, 3), "mat", 0.8 * sq3 / math.sqrt(3 * D)
+    yield e + ".conv2.weight", (D, D, 3), "mat", 2.0 * sq3 / math.sqrt(3 * D)
     yield e + ".conv2.bias", (D,), "vec", 0.1
     yield e + ".embed_positions.weight", (d.n_audio_ctx, D), "sin", 1.0
     for i in range(d.enc_layers):
         p = f"{e}.layers.{i}"
-        yield from attn(p + ".self_attn")
+        yield from attn(p + ".self_attn", enc_res)
         yield from ln(p + ".self_attn_layer_norm")
         yield from lin(p + ".fc1", F, D)
-        yield from lin(p + ".fc2", D, F)
+        yield from lin(p + ".fc2", D, F, gain=enc_res)
         yield from ln(p + ".final_layer_norm")
     yield from ln(e + ".layer_norm")
 
     q = "model.decoder"
     # Tied embeddings give the fed token's own logit a +|E_tok|^2/sigma bonus; keep it near
     # two standard deviations of the other logits so greedy output does not lock onto repeats.
-    sigma_x = math.sqrt(1.0 + 1.9 * d.dec_layers)
+    sigma_x = math.sqrt(1.0 + 0.64 * min(3 * d.dec_layers, 4))
     yield q + ".embed_tokens.weight", (d.vocab, D), "mat", 1.0 * sigma_x * sq3 / math.sqrt(D)
     yield q + ".embed_positions.weight", (d.n_text_ctx, D), "mat", 1.0 * sq3
     for i in range(d.dec_layers):
         p = f"{q}.layers.{i}"
-        yield from attn(p + ".self_attn")
+        yield from attn(p + ".self_attn", dec_res)
         yield from ln(p + ".self_attn_layer_norm")
-        yield from attn(p + ".encoder_attn")
+        yield from attn(p + ".encoder_attn", dec_res)
         yield from ln(p + ".encoder_attn_layer_norm")
         yield from lin(p + ".fc1", F, D)
-        yield from lin(p + ".fc2", D, F)
+        yield from lin(p + ".fc2", D, F, gain=dec_res)
         yield from ln(p + ".final_layer_norm")
     yield from ln(q + ".layer_norm")
 
@@ -150,26 +157,42 @@ def make_weights_torch(d: WhisperDims, seed: int = 1234, device="cpu") -> dict:
     return out
 
 
+def _voices(b: int, seed: int):
+    """Three frequency-swept, amplitude-modulated voices per chunk; parameters depend on (chunk, seed)."""
+    out = []
+    for v in range(3):
+        h = (b * 2654435761 + seed * 40503 + v * 97) & 0xFFFFFFFF
+        f0 = 150.0 + (h % 2900)                      # start frequency, Hz
+        sweep = ((h >> 8) % 1200) - 600.0            # Hz over the chunk
+        am = 0.3 + ((h >> 16) % 50) / 10.0           # envelope rate, Hz
+        amp = 0.04 + ((h >> 24) % 8) / 100.0
+        out.append((f0, sweep, am, amp))
+    return out
+
+
 def make_pcm_np(batch: int, seed: int = 0, n: int = CHUNK_SAMPLES) -> np.ndarray:
-    """Synthetic audio: hash noise (std 0.1) plus two tones whose pitch depends on the row."""
+    """Synthetic audio: a low hash-noise floor (std 0.01) plus three swept, amplitude-modulated
+    tones whose parameters differ per chunk, so that chunks have clearly different spectrograms."""
     t = np.arange(n, dtype=np.float64) / 16000.0
     rows = []
     for b in range(batch):
-        noise = hash_uniform_np(n, f"pcm.{b}", seed) * np.float32(0.1 * 2.0 * math.sqrt(3.0))
-        f1, f2 = 440.0 * (1 + 0.07 * b), 1000.0 * (1 + 0.03 * b)
-        tone = 0.05 * np.sin(2 * np.pi * f1 * t) + 0.03 * np.sin(2 * np.pi * f2 * t)
-        rows.append(noise + tone.astype(np.float32))
-    return np.stack(rows).astype(np.float32)
+        x = (hash_uniform_np(n, f"pcm.{b}", seed) * np.float32(0.01 * 2.0 * math.sqrt(3.0))).astype(np.float64)
+        for f0, sweep, am, amp in _voices(b, seed):
+            phase = 2 * np.pi * (f0 * t + 0.5 * sweep * t * t / 30.0)
+            x = x + amp * (0.5 + 0.5 * np.sin(2 * np.pi * am * t)) * np.sin(phase)
+        rows.append(x.astype(np.float32))
+    return np.stack(rows)
 
 
 def make_pcm_torch(batch: int, seed: int = 0, device="cpu", n: int = CHUNK_SAMPLES):
-    """Same construction as make_pcm_np, built on `device` (tones differ in the last float32 bit)."""
+    """Same construction as make_pcm_np, built on `device` (may differ in the last float32 bit)."""
     import torch
     t = torch.arange(n, dtype=torch.float64, device=device) / 16000.0
     rows = []
     for b in range(batch):
-        noise = hash_uniform_torch(n, f"pcm.{b}", seed, device) * (0.1 * 2.0 * math.sqrt(3.0))
-        f1, f2 = 440.0 * (1 + 0.07 * b), 1000.0 * (1 + 0.03 * b)
-        tone = 0.05 * torch.sin(2 * math.pi * f1 * t) + 0.03 * torch.sin(2 * math.pi * f2 * t)
-        rows.append(noise + tone.to(torch.float32))
+        x = (hash_uniform_torch(n, f"pcm.{b}", seed, device) * (0.01 * 2.0 * math.sqrt(3.0))).to(torch.float64)
+        for f0, sweep, am, amp in _voices(b, seed):
+            phase = 2 * math.pi * (f0 * t + 0.5 * sweep * t * t / 30.0)
+            x = x + amp * (0.5 + 0.5 * torch.sin(2 * math.pi * am * t)) * torch.sin(phase)
+        rows.append(x.to(torch.float32))
     return torch.stack(rows).contiguous()

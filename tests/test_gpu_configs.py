@@ -1,0 +1,114 @@
+"""Parity cases at the sizes BASELINE.json's configs name (beyond the micro/tiny fixtures).
+
+config 2: whisper-small fp16, batch 8          -> logits and ids against the oracle
+config 3: whisper-large-v3 fp16, batch 16      -> one chunk against the oracle at full size, and
+                                                  size-independent properties at batch 16
+config 4: long audio sharded over ranks        -> 120-chunk bookkeeping (CPU side is in test_host.py)
+Weights are generated on the GPU with the same hash the numpy generator uses.
+"""
+import numpy as np
+import pytest
+
+import manual_whisper_amd as mw
+from manual_whisper_amd import synth
+from manual_whisper_amd.decode_options import synthetic_options
+from oracle.whisper_ref import WhisperOracle, log_mel
+
+from test_gpu_parity import ENC_ATOL, LOGIT_ATOL, assert_ids_match_up_to_ties
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_and_oracle(name, max_batch, with_oracle=True):
+    import torch
+    from manual_whisper_amd.engine import Engine
+    dims = mw.get_dims(name)
+    wt = synth.make_weights_torch(dims, 1234, torch.device("cuda", 0))
+    eng = Engine(dims, 0, max_batch)
+    eng.load_weights(wt)
+    orc = WhisperOracle(dims, {k: v.float().cpu().numpy() for k, v in wt.items()}) if with_oracle else None
+    del wt
+    torch.cuda.empty_cache()
+    return dims, eng, orc
+
+
+def test_config2_small_batch8():
+    dims, eng, orc = _engine_and_oracle("small", 8)
+    try:
+        opts = synthetic_options(dims, max_new=6)
+        eng.set_decode_options(opts)
+        pcm = synth.make_pcm_np(8, seed=202)
+        mel_ref = log_mel(pcm, dims.n_mels)
+        enc_ref = orc.encode(mel_ref)
+        enc = eng.encode(8, mel=mel_ref)
+        assert np.abs(enc - enc_ref).max() < ENC_ATOL
+        toks = np.tile(np.asarray(opts.prompt + (11, 22, 33), np.int32)[None], (8, 1))
+        got = eng.decode_forced(toks)
+        want = orc.forced_logits(enc_ref, toks)
+        assert np.abs(got - want).max() < LOGIT_ATOL
+        ids, lens = eng.transcribe_batch(pcm)
+        wi, wl = orc.greedy(enc_ref, list(opts.prompt), opts.max_new, opts.eot, opts.suppress, opts.begin_suppress)[:2]
+        assert_ids_match_up_to_ties(ids, wi, orc.last_margins)
+        assert (ids == wi).all(axis=1).sum() >= 6
+    finally:
+        eng.close()
+
+
+@pytest.fixture(scope="module")
+def large():
+    dims, eng, orc = _engine_and_oracle("large-v3", 16)
+    yield dims, eng, orc
+    eng.close()
+
+
+def test_config3_large_v3_one_chunk_vs_oracle(large):
+    """Full-size architecture, one 30 s chunk, 6 sampled tokens: encoder output, logits and ids."""
+    dims, eng, orc = large
+    opts = synthetic_options(dims, max_new=6, suppress_eot=True)
+    eng.set_decode_options(opts)
+    pcm = synth.make_pcm_np(1, seed=303)
+    mel_ref = log_mel(pcm, dims.n_mels)
+    mel = eng.logmel(pcm)
+    assert np.abs(mel - mel_ref).max() < 1e-4
+    enc_ref = orc.encode(mel_ref)
+    enc = eng.encode(1)
+    assert np.abs(enc - enc_ref).max() < 2 * ENC_ATOL              # 32 layers deep
+    ids, lens, logits = eng.decode_greedy(1, want_logits=True)
+    wi, wl, wlog = orc.greedy(enc_ref, list(opts.prompt), opts.max_new, opts.eot, opts.effective_suppress(),
+                              opts.begin_suppress, return_logits=True)
+    assert np.abs(logits[0] - wlog[0]).max() < 2 * LOGIT_ATOL
+    assert_ids_match_up_to_ties(ids, wi, orc.last_margins)
+
+
+def test_config3_large_v3_batch16_properties(large):
+    """Batch 16 at full size: run-to-run identical, independent of batch position and batch size,
+    identical from a forked engine."""
+    dims, eng, _ = large
+    opts = synthetic_options(dims, max_new=24, suppress_eot=True)
+    eng.set_decode_options(opts)
+    pcm = synth.make_pcm_np(16, seed=404)
+    a, la = eng.transcribe_batch(pcm)
+    b, _ = eng.transcribe_batch(pcm)
+    assert (a == b).all() and (la == 24).all()
+    rev, _ = eng.transcribe_batch(np.ascontiguousarray(pcm[::-1]))
+    assert (rev[::-1] == a).all()
+    one, _ = eng.transcribe_batch(pcm[7:8])
+    assert (one[0] == a[7]).all()
+    fork = eng.fork()
+    try:
+        c, _ = fork.transcribe_batch(pcm)
+        assert (c == a).all()
+    finally:
+        fork.close()
+    assert len({tuple(r) for r in a}) > 1, "all 16 chunks decoded to the same ids"
+
+
+def test_config4_long_audio_chunk_bookkeeping():
+    """One hour = 120 chunks: spans, batching and rank shards tile the recording exactly."""
+    from manual_whisper_amd import parallel, scheduler
+    n = 16000 * 3600
+    chunks, spans = scheduler.split_chunks(np.zeros(n, np.float32))
+    assert chunks.shape == (120, 480000) and spans[0] == (0.0, 30.0) and spans[-1] == (3570.0, 3600.0)
+    shards = [parallel.shard_range(120, r, 8) for r in range(8)]
+    assert [b - a for a, b in shards] == [15] * 8
+    assert scheduler.batches_of(15, 16) == [(0, 15)]

@@ -99,16 +99,23 @@ def main():
     torch.set_num_threads(8)
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    for name, B, max_new in (("micro", 2, 24), ("tiny", 2, 12)):
+    for name, B, max_new in (("micro", 2, 16), ("tiny", 2, 12)):
         dims = mw.get_dims(name)
         weights = synth.make_weights_np(dims, seed=1234)
-        pcm = synth.make_pcm_np(B, seed=0)
         opts = synthetic_options(dims)
         model = build_hf(dims, weights)
-        mel = hf_mel(pcm, dims.n_mels)
-        with torch.no_grad():
-            enc = model.model.encoder(torch.from_numpy(mel)).last_hidden_state.numpy()
-        ids, lens, margins, step_logits, prompt_logits = hf_greedy(model, enc, opts, max_new)
+        # Identical greedy ids are only a fair demand where the fp32 path itself is not on a knife's
+        # edge: take the first audio seed whose smallest top-1 margin is healthy, and record it.
+        for pcm_seed in range(120):
+            pcm = synth.make_pcm_np(B, seed=pcm_seed)
+            mel = hf_mel(pcm, dims.n_mels)
+            with torch.no_grad():
+                enc = model.model.encoder(torch.from_numpy(mel)).last_hidden_state.numpy()
+            ids, lens, margins, step_logits, prompt_logits = hf_greedy(model, enc, opts, max_new)
+            if margins[margins > 0].min() >= 0.03:
+                break
+        else:
+            raise SystemExit(f"{name}: no audio seed with a healthy margin")
         topk = 8
         order = np.argsort(-step_logits, axis=2)[:, :, :topk]
         topv = np.take_along_axis(step_logits, order, axis=2)
@@ -116,7 +123,7 @@ def main():
         probe_cols = np.arange(0, dims.vocab, max(1, dims.vocab // 64))[:64]
         np.savez_compressed(
             os.path.join(outdir, f"{name}.npz"),
-            config=np.array(name), seed=np.array(1234), pcm_seed=np.array(0), batch=np.array(B),
+            config=np.array(name), seed=np.array(1234), pcm_seed=np.array(pcm_seed), batch=np.array(B),
             mel_sub=mel[:, :, ::16], mel_max=mel.max(axis=(1, 2)), mel_mean=mel.mean(axis=(1, 2)),
             enc_sub=enc[:, ::25, :], enc_absmean=np.abs(enc).mean(),
             prompt=np.array(opts.prompt, np.int32), eot=np.array(opts.eot),
@@ -127,7 +134,7 @@ def main():
             prompt_probe=prompt_logits[:, :, probe_cols].astype(np.float32),
             logit_std=np.array(step_logits.std(), np.float32),
         )
-        print(f"{name}: ids[0]={ids[0][:12]} lens={lens} min margin={margins[margins > 0].min():.4f} "
+        print(f"{name}: pcm_seed={pcm_seed} ids[0]={ids[0][:12]} lens={lens} min margin={margins[margins > 0].min():.4f} "
               f"logit std={step_logits.std():.3f} enc |mean|={np.abs(enc).mean():.3f}")
 
 

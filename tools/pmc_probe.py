@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Development aid for hardware-counter runs: a torch-free process (MW_SYSTEM_HIP=1, system ROCm
+runtime) that runs a few large-v3 decode steps at batch 16 on random weights.  Used as
+`rocprofv3 --pmc FETCH_SIZE -- python3 tools/pmc_probe.py` (and WRITE_SIZE in its own pass)."""
+import os, sys
+os.environ["MW_SYSTEM_HIP"] = "1"
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import manual_whisper_amd as mw
+from manual_whisper_amd import synth
+from manual_whisper_amd.decode_options import synthetic_options
+from manual_whisper_amd.engine import Engine
+
+B = 16
+dims = mw.get_dims("large-v3")
+rng = np.random.default_rng(0)
+eng = Engine(dims, 0, B)
+w = {}
+for name, shape, kind, scale in synth.tensor_specs(dims):
+    n = int(np.prod(shape))
+    a = rng.standard_normal(n, dtype=np.float32) * np.float32(scale / 3.46)
+    if kind == "gamma":
+        a += 1
+    w[name] = (a.astype(np.float16) if kind in ("mat", "sin") else a).reshape(shape)
+eng.load_weights(w)
+del w
+eng.set_decode_options(synthetic_options(dims, max_new=int(os.environ.get("MW_NEW", "3")), suppress_eot=True))
+mel = rng.standard_normal((B, dims.n_mels, 3000), dtype=np.float32) * 0.3
+eng.encode(B, mel=mel, want_output=False)
+eng.set_option("graph", 0)
+eng.decode_greedy(B)
+print("done", eng.stage_ms())
