@@ -31,6 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, spec
+# HBM bytes per launch of the cross-attention decode kernel at batch 16 from the PMC counters
+# (2 x FETCH_SIZE 60312.6 KB + WRITE_SIZE 530 KB); algorithmic bytes are 122.88 MB.
+XATTN_TRAFFIC_BYTES = 2 * 60312.6 * 1024 + 530.0 * 1024
 BATCH = 16
 NEW_TOKENS = 128
 MODEL = "large-v3"
@@ -165,9 +168,10 @@ def main():
                        "parallelism": f"dp{world} over chunks, one all_gather of ids at the end"},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items() if k != "decode_steps"},
             "decode_steps_per_step": int(stage.get("decode_steps", 0)),
-            "roofline": {"kernel": "dec_attn_kernel<1504> (decode cross-attention, one launch per layer per token)",
+            "roofline": {"kernel": "dec_attn_kernel<256,12,4> (decode cross-attention, one launch per layer per token)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": XATTN_TRAFFIC_BYTES,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/round1_hbm_counters.csv",
                          "bytes_per_launch": ca_bytes, "avg_launch_us": round(ca_ms * 1e3, 2)},
         }
         if weights_np is not None:
