@@ -31,12 +31,44 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, spec
+MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X dense fp16 MFMA, spec (no sparsity)
 # HBM bytes per launch of the cross-attention decode kernel at batch 16 from the PMC counters
 # (2 x FETCH_SIZE 60312.6 KB + WRITE_SIZE 530 KB); algorithmic bytes are 122.88 MB.
 XATTN_TRAFFIC_BYTES = 2 * 60312.6 * 1024 + 530.0 * 1024
 BATCH = 16
 NEW_TOKENS = 128
 MODEL = "large-v3"
+
+
+def stage_rooflines(dims, batch, n_prompt, n_new, ms):
+    """Algorithmic bytes / flops of each stage of one step over the stage's measured time (one
+    engine alone on the GPU).  2*M*N*K per contraction, softmax/LayerNorm/GELU not counted."""
+    D, F, T = dims.d_model, dims.ffn_dim, dims.n_audio_ctx
+    mel_bytes = batch * (480000 * 4 + dims.n_mels * 3000 * 2)
+    enc_flop = batch * (2 * 3000 * D * 3 * dims.n_mels + 2 * T * D * 3 * D
+                        + dims.enc_layers * (2 * T * (4 * D * D + 2 * D * F) + 4 * T * T * D))
+    ckv_flop = batch * 2 * T * D * 2 * D * dims.dec_layers
+    steps = n_prompt + n_new - 1
+    w_bytes = dims.dec_layers * (6 * D * D + 2 * D * F) * 2 + dims.vocab * D * 2
+    ckv_bytes = batch * dims.dec_layers * 2 * T * D * 2
+    self_bytes = sum(batch * dims.dec_layers * 2 * (t + 1) * D * 2 for t in range(steps))
+    dec_bytes = steps * (w_bytes + ckv_bytes) + self_bytes
+
+    def hbm(nbytes, t_ms):
+        a = nbytes / (t_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4)}
+
+    def mfma(flop, t_ms):
+        a = flop / (t_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(a, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(a / MFMA_F16_PEAK_TFLOPS, 4)}
+
+    out = {"logmel": hbm(mel_bytes, ms["logmel"]), "encoder": mfma(enc_flop, ms["encoder"]),
+           "cross_kv": mfma(ckv_flop, ms["cross_kv"]), "decode": hbm(dec_bytes, ms["decode"])}
+    floor_ms = (mel_bytes + dec_bytes) / (HBM_PEAK_GBS * 1e6) + (enc_flop + ckv_flop) / (MFMA_F16_PEAK_TFLOPS * 1e9)
+    out["sum_of_stage_floors_ms"] = round(floor_ms, 2)
+    out["solo_step_ms"] = round(sum(ms[k] for k in ("logmel", "encoder", "cross_kv", "decode")), 2)
+    return out
 
 
 def cpu_baseline(dims, weights_np, opts, gpu_ids_fn):
@@ -148,6 +180,9 @@ def main():
         for k, v in e.stage_ms().items():
             stage[k] = stage.get(k, 0.0) + v / len(pool.engines)
 
+    eng.transcribe_batch(pcms[0])               # one step with the GPU to itself: per-stage rooflines
+    solo_ms = eng.stage_ms()
+
     # dominant kernel: decode-time cross-attention, HIP events on the engine's own stream
     ca_ms, ca_bytes = eng.profile_cross_attention(BATCH, iters=256)
     achieved = ca_bytes / (ca_ms * 1e-3) / 1e9
@@ -168,6 +203,7 @@ def main():
                        "parallelism": f"dp{world} over chunks, one all_gather of ids at the end"},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items() if k != "decode_steps"},
             "decode_steps_per_step": int(stage.get("decode_steps", 0)),
+            "stage_roofline": stage_rooflines(dims, BATCH, len(opts.prompt), NEW_TOKENS, solo_ms),
             "roofline": {"kernel": "dec_attn_kernel<256,12,4> (decode cross-attention, one launch per layer per token)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": XATTN_TRAFFIC_BYTES,

@@ -73,6 +73,7 @@ struct mw_ctx {
     int *forced = nullptr, *out_ids = nullptr, *out_len = nullptr, *finished = nullptr;
     int forced_cap = 0;
     float* xpartial = nullptr; int* xtickets = nullptr;    // cross-attention key-range partials + ticket counters
+    float* skpartial = nullptr; int* sktickets = nullptr;  // split-K partial tiles + ticket counters of the residual projections
 
     // decode options
     std::vector<int32_t> prompt;
@@ -235,6 +236,7 @@ static int alloc_work(mw_ctx* ctx) {
     ALLOC(ctx->part_val, B * (size_t)ctx->n_parts); ALLOC(ctx->part_idx, B * (size_t)ctx->n_parts);
     ALLOC(ctx->mask_first, (size_t)d.vocab, true); ALLOC(ctx->mask_rest, (size_t)d.vocab, true);
     ALLOC(ctx->xpartial, B * H * kXattnSplit * 68); ALLOC(ctx->xtickets, B * H, true);
+    ALLOC(ctx->skpartial, splitk_partial_floats(D)); ALLOC(ctx->sktickets, splitk_groups(D), true);
     ctx->forced_cap = d.n_text_ctx;
     ALLOC(ctx->forced, B * (size_t)ctx->forced_cap);
     ALLOC(ctx->out_ids, B * (size_t)d.n_text_ctx); ALLOC(ctx->out_len, B); ALLOC(ctx->finished, B);
@@ -677,6 +679,8 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
         GemvParams p{};
         p.B = B; p.N = N; p.K = K; p.W = w.w; p.bias = w.b; p.scale = 1.f; p.scale_ncols = 0; p.gelu = 0;
         p.H = H; p.D = D; p.Tctx = Tc; p.st = ctx->st; p.ln_scratch = ctx->dxn; p.nv = 16;
+        p.sk_partial = ctx->skpartial; p.sk_partial_floats = splitk_partial_floats(D);
+        p.sk_tickets = ctx->sktickets; p.sk_groups = splitk_groups(D);
         return p;
     };
     for (int li = 0; li < d.dec_layers; ++li) {

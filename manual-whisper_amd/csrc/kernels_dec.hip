@@ -201,6 +201,129 @@ __global__ void gemv_kernel(GemvParams p) {
     }
 }
 
+// ------------------------------------------------------------------ split-K residual GEMM
+// x[b][n] += bias[n] + sum_k X[b][k] * W[n][k] for the three residual projections of a layer.
+// In gemv_kernel every workgroup reads ALL of X (16 rows x K fp16), which for K = 5120 is more
+// than its own weight slice: the launch is bound by activation re-reads, not by the weight stream.
+// Here a workgroup owns 16*R weight rows and ONE of S ranges of K, so X is read N/(16R) times in
+// total instead of N/8 times.  The S partial tiles of a row group are combined by whichever
+// workgroup arrives last (same hand-off as the cross-attention merge above: one wave publishes with
+// agent-scope stores, drains them, takes a ticket; the last ticket holder reads all S tiles back
+// with agent-scope loads and sums them in index order, so the result is independent of arrival
+// order), adds bias and residual, writes x and re-arms the ticket.
+constexpr int kSplitKWaves = 4;
+constexpr int kSplitKMax = 8;
+
+template <int MT, int KPW, int R>
+__global__ __launch_bounds__(kSplitKWaves * 64) void gemv_splitk_kernel(GemvParams p, int ks_per) {
+    constexpr int NW = kSplitKWaves, NT = R * MT;       // NT accumulator tiles per wave
+    __shared__ float4v red[NW][NT][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int S = gridDim.y, split = blockIdx.y, rg = blockIdx.x;
+    const int n0 = rg * 16 * R;
+    const int nks = p.K >> 5;
+    const int k0 = split * ks_per;
+    const int kend = min(nks, k0 + ks_per);             // > k0: the launcher never creates an empty range
+
+    uint4 wreg[R][KPW];
+    half8 xfrag[MT][KPW];
+    bool kval[KPW];
+#pragma unroll
+    for (int c = 0; c < KPW; ++c) {
+        const int ks = k0 + wave + NW * c;
+        kval[c] = ks < kend;
+        const int kc = min(ks, kend - 1) * 32 + fg * 8;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            wreg[r][c] = *reinterpret_cast<const uint4*>(p.W + (long)(n0 + r * 16 + fr) * p.K + kc);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            xfrag[t][c] = *reinterpret_cast<const half8*>(p.xin16 + (long)min(t * 16 + fr, p.B - 1) * p.K + kc);
+    }
+    // epilogue operands of the merging wave (only the last arriver uses them)
+    float4 bias4[R], res4[NT];
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = n0 + r * 16 + 4 * fg;
+            bias4[r] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                res4[r * MT + t] = *reinterpret_cast<const float4*>(p.out32 + (long)min(t * 16 + fr, p.B - 1) * p.N + n);
+        }
+    }
+
+    float4v acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = float4v{0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < KPW; ++c) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint4 w = wreg[r][c];
+            if (!kval[c]) w = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[r * MT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&w), xfrag[t][c], acc[r * MT + t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        acc[i] = red[0][i][lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) acc[i] += red[w][i][lane];
+    }
+    // publish: slab[rg][split][NT*4][64] floats, every store a contiguous 256 B per wave
+    float* slab = p.sk_partial + (long)rg * S * (NT * 4 * 64);
+    if (S > 1) {
+        float* mine = slab + (long)split * (NT * 4 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __hip_atomic_store(mine + (i * 4 + j) * 64, acc[i][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's tile has left the CU
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(p.sk_tickets + rg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __shfl(ticket, 0);
+        if (ticket != S - 1) return;
+        // last arriver: all S tiles of this row group are complete; sum in index order
+        float part[kSplitKMax][NT * 4];
+#pragma unroll
+        for (int i = 0; i < kSplitKMax; ++i) {
+            const float* src = slab + (long)min(i, S - 1) * (NT * 4 * 64) + lane;
+#pragma unroll
+            for (int e = 0; e < NT * 4; ++e)
+                part[i][e] = __hip_atomic_load(src + e * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < kSplitKMax; ++i) v += i < S ? part[i][e] : 0.f;
+            acc[e >> 2][e & 3] = v;
+        }
+        if (lane == 0) __hip_atomic_store(p.sk_tickets + rg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int n = n0 + r * 16 + 4 * fg;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = t * 16 + fr, i = r * MT + t;
+            if (m >= p.B) continue;
+            *reinterpret_cast<float4*>(p.out32 + (long)m * p.N + n) =
+                make_float4(res4[i].x + (acc[i][0] + bias4[r].x), res4[i].y + (acc[i][1] + bias4[r].y),
+                            res4[i].z + (acc[i][2] + bias4[r].z), res4[i].w + (acc[i][3] + bias4[r].w));
+        }
+    }
+}
+
 // ------------------------------------------------------------------ logits + partial argmax
 // logits[b][n] = xn[b] . E[n] over the tied token embedding (modeling_whisper.py:1080).
 // Workgroup = 8 waves, each a tile of 16 vocabulary rows over the full K; the normalised
@@ -559,6 +682,35 @@ bool launch_gemv_mt(const GemvParams& p, hipStream_t s) {
     }
 }
 
+template <int MT, int R>
+bool launch_splitk_r(const GemvParams& p, int S, hipStream_t s) {
+    const int nks = p.K / 32;
+    const int ks_per = (nks + S - 1) / S;
+    S = (nks + ks_per - 1) / ks_per;                    // drop ranges that would be empty
+    const int kpw = (ks_per + kSplitKWaves - 1) / kSplitKWaves;
+    const dim3 grid(p.N / (16 * R), S), block(kSplitKWaves * 64);
+    switch (kpw) {
+#define MW_SK_CASE(KPW) case KPW: hipLaunchKernelGGL((gemv_splitk_kernel<MT, KPW, R>), grid, block, 0, s, p, ks_per); return true;
+        MW_SK_CASE(1) MW_SK_CASE(2) MW_SK_CASE(3) MW_SK_CASE(4) MW_SK_CASE(5) MW_SK_CASE(6) MW_SK_CASE(7) MW_SK_CASE(8)
+#undef MW_SK_CASE
+        default: return false;
+    }
+}
+
+// Residual projection with K >= 2N (the MLP's second matrix): 32-row groups and as many K ranges as
+// give about one workgroup per CU.  Square projections (K = N = d_model) stay on gemv_kernel:
+// their activation re-reads are 4x smaller and the merge hand-off costs more than it saves
+// (measured: 3 ranges of 16-row groups slowed a large-v3 step by 1.3 %).
+// Returns false when the shape does not fit; the plain kernel takes over.
+bool launch_splitk(const GemvParams& p, int mt, hipStream_t s) {
+    static const bool off = getenv("MW_SPLITK_OFF") != nullptr;
+    if (off || !p.sk_partial || !p.sk_tickets || p.K % 32 || p.K < 2 * p.N || p.N % 32) return false;
+    const int groups = p.N / 32;
+    const int S = max(1, min(240 / groups, min(kSplitKMax, p.K / 32)));
+    if (groups > p.sk_groups || (long)groups * S * 2 * mt * 256 > p.sk_partial_floats) return false;
+    return mt == 1 ? launch_splitk_r<1, 2>(p, S, s) : launch_splitk_r<2, 2>(p, S, s);
+}
+
 }  // namespace
 
 int gemv_logits_parts(int N) { return ((N + 15) / 16 + 7) / 8; }
@@ -579,6 +731,7 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
     static const int nv_narrow = getenv("MW_NV_NARROW") ? atoi(getenv("MW_NV_NARROW")) : 8;
     static const int nv_wide = getenv("MW_NV_WIDE") ? atoi(getenv("MW_NV_WIDE")) : 16;
     p.nv = p.N <= 2048 ? nv_narrow : nv_wide;
+    if (p.out_mode == GV_RESID && !p.ln_g && launch_splitk(p, mt, s)) return;
     if (mt == 1) (void)launch_gemv_mt<1>(p, s); else (void)launch_gemv_mt<2>(p, s);
 }
 

@@ -20,6 +20,9 @@
 // k=3 convolutions of the encoder stem run as plain GEMMs over a time-major padded buffer.
 #include "mw_kernels.h"
 
+#include <stdlib.h>
+#include <type_traits>
+
 namespace mw {
 
 namespace {
@@ -30,55 +33,104 @@ __device__ __forceinline__ int swz(int row, int chunk) {      // offset in halfs
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// GELU(x) = x * Phi(x) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the
+// fp16 rounding of the result); the negative side uses 1 + erf(z) = poly * exp(-z^2) directly, so
+// there is no cancellation.  12 instructions instead of the ~50 of erff: the epilogue is straight
+// line code executed once per tile, and its size is what it costs.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float q = fmaf(1.061405429f, t, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    const float h = 0.5f * q * t * __expf(-z * z);       // 0.5 * (1 - erf(z))
+    return x * (x >= 0.f ? 1.0f - h : h);
+}
 
 // Fused epilogue: lane holds C[m][n..n+3], m = m0 + wm*MI*16 + j*16 + fr, n = n0 + wn*64 + i*16 + 4*fg.
-template <int MI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc)[4][MI], int m0, int n0, int wm, int wn,
-                                              int fr, int fg) {
+// Output mode and GELU are compile-time here (one uniform switch at the call site): the unrolled
+// MI x 4 body must stay small, or instruction fetch dominates the tile.
+template <int MI, int OUT, bool GELU>
+__device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, float4v (&acc)[4][MI], int m0, int n0, int wm, int wn,
+                                                int fr, int fg) {
+    float4 bv[4];
+    float sc[4];
+    bool n_ok[4];
+    long col[4];            // column part of the output offset
+    int sec[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * fg;
+        n_ok[i] = n < p.N;                              // N is a multiple of 4
+        const int nc = n_ok[i] ? n : 0;
+        bv[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sc[i] = n < p.scale_ncols ? p.scale : 1.0f;
+        if constexpr (OUT == OUT_F16 || OUT == OUT_RESID_F32) {
+            col[i] = nc; sec[i] = 0;
+        } else {
+            sec[i] = nc / p.D;
+            const int nn = nc - sec[i] * p.D;
+            const int hh = nn >> 6, e = nn & 63;
+            if (OUT == OUT_QKV_SPLIT && sec[i] == 2) col[i] = ((long)hh * 64 + e) * p.Tpad;       // V^T [B][H][64][Tpad]
+            else col[i] = (long)hh * p.T * 64 + e;                                                // [B][H][T][64]
+        }
+    }
+    const bool flat = p.c_rows_per_batch >= p.M;
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
         const int m = m0 + wm * MI * 16 + j * 16 + fr;
-        if (m >= p.M) continue;
-        int bb = 0, tt = 0;
-        if (p.out_mode >= OUT_QKV_SPLIT) { bb = m / p.T; tt = m - bb * p.T; }
+        const bool m_ok = m < p.M;
+        long row, rowT = 0;     // row part of the output offset (rowT: the same for the transposed V)
+        if constexpr (OUT == OUT_F16 || OUT == OUT_RESID_F32) {
+            row = flat ? (long)m * p.ldc : (long)(m / p.c_rows_per_batch) * p.c_batch_stride + (long)(m % p.c_rows_per_batch) * p.ldc;
+        } else {
+            const int bb = m / p.T, tt = m - bb * p.T;
+            row = ((long)bb * p.H * p.T + tt) * 64;
+            rowT = (long)bb * p.H * 64 * p.Tpad + tt;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + 4 * fg;
-            if (n >= p.N) continue;                     // N is a multiple of 4
+            if (!(m_ok && n_ok[i])) continue;
             float4v v = acc[i][j];
-            if (p.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
-            if (n < p.scale_ncols) { v[0] *= p.scale; v[1] *= p.scale; v[2] *= p.scale; v[3] *= p.scale; }
-            if (p.gelu) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
-            if (p.out_mode == OUT_RESID_F32) {
-                float* c = reinterpret_cast<float*>(p.C) + (long)(m / p.c_rows_per_batch) * p.c_batch_stride +
-                           (long)(m % p.c_rows_per_batch) * p.ldc + n;
+            v[0] = (v[0] + bv[i].x) * sc[i]; v[1] = (v[1] + bv[i].y) * sc[i];
+            v[2] = (v[2] + bv[i].z) * sc[i]; v[3] = (v[3] + bv[i].w) * sc[i];
+            if constexpr (GELU) { v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]); }
+            if constexpr (OUT == OUT_RESID_F32) {
+                float* c = reinterpret_cast<float*>(p.C) + row + col[i];
                 float4 o = *reinterpret_cast<float4*>(c);
                 o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
                 *reinterpret_cast<float4*>(c) = o;
             } else {
-                half4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                if (p.out_mode == OUT_F16) {
-                    f16* c = reinterpret_cast<f16*>(p.C) + (long)(m / p.c_rows_per_batch) * p.c_batch_stride +
-                             (long)(m % p.c_rows_per_batch) * p.ldc + n;
-                    *reinterpret_cast<half4*>(c) = h;
+                const half4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                if constexpr (OUT == OUT_F16) {
+                    *reinterpret_cast<half4*>(reinterpret_cast<f16*>(p.C) + row + col[i]) = h;
+                } else if (OUT == OUT_QKV_SPLIT && sec[i] == 2) {
+                    f16* c = p.v + rowT + col[i];
+                    c[0] = h[0]; c[p.Tpad] = h[1]; c[2L * p.Tpad] = h[2]; c[3L * p.Tpad] = h[3];
                 } else {
-                    const int sec = n / p.D, nn = n - sec * p.D;
-                    const int hh = nn >> 6, e = nn & 63;
-                    const long bh = (long)bb * p.H + hh;
-                    if (p.out_mode == OUT_QKV_SPLIT && sec == 2) {           // V transposed: [B][H][64][Tpad]
-                        f16* c = p.v + (bh * 64 + e) * p.Tpad + tt;
-                        c[0] = h[0]; c[p.Tpad] = h[1]; c[2L * p.Tpad] = h[2]; c[3L * p.Tpad] = h[3];
-                    } else {
-                        f16* base = (p.out_mode == OUT_QKV_SPLIT) ? (sec == 0 ? p.q : p.k) : (sec == 0 ? p.k : p.v);
-                        *reinterpret_cast<half4*>(base + (bh * p.T + tt) * 64 + e) = h;
-                    }
+                    f16* base = (OUT == OUT_QKV_SPLIT) ? (sec[i] == 0 ? p.q : p.k) : (sec[i] == 0 ? p.k : p.v);
+                    *reinterpret_cast<half4*>(base + row + col[i]) = h;
                 }
             }
         }
+    }
+}
+
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc)[4][MI], int m0, int n0, int wm, int wn, int fr,
+                                              int fg) {
+    switch (p.out_mode) {
+        case OUT_F16:
+            if (p.gelu) gemm_epilogue_t<MI, OUT_F16, true>(p, acc, m0, n0, wm, wn, fr, fg);
+            else gemm_epilogue_t<MI, OUT_F16, false>(p, acc, m0, n0, wm, wn, fr, fg);
+            break;
+        case OUT_RESID_F32:
+            if (p.gelu) gemm_epilogue_t<MI, OUT_RESID_F32, true>(p, acc, m0, n0, wm, wn, fr, fg);
+            else gemm_epilogue_t<MI, OUT_RESID_F32, false>(p, acc, m0, n0, wm, wn, fr, fg);
+            break;
+        case OUT_QKV_SPLIT: gemm_epilogue_t<MI, OUT_QKV_SPLIT, false>(p, acc, m0, n0, wm, wn, fr, fg); break;
+        default: gemm_epilogue_t<MI, OUT_KV_SPLIT, false>(p, acc, m0, n0, wm, wn, fr, fg); break;
     }
 }
 
@@ -235,12 +287,192 @@ void launch_t(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<MI, GLDS>), dim3(nt), dim3(256), lds, s, p);
 }
 
+// ------------------------------------------------------------------ 256x256x64 tile, 8 waves
+// For the big encoder products (>= one 256x256 tile per CU).  One workgroup per CU: 8 waves as
+// 2 (M) x 4 (N), each 128x64 of C in 32 accumulator tiles.  LDS holds two K-tiles, each as four
+// 16 KiB half-tiles (A0, A1, B0, B1): half h of A is rows wr*128 + h*64 + [0,64) of both wave rows,
+// half h of B is columns wc*64 + h*32 + [0,32) of all four wave columns, so that a quadrant
+// (ha, hb) of every wave's output needs exactly half-tiles A[ha] and B[hb].
+//
+// A K-tile is four phases, one quadrant each, in the order (0,0) (0,1) (1,1) (1,0); a phase is
+//     ds_read the half-tile(s) the quadrant adds | issue ONE half-tile of LDS-DMA prefetch |
+//     counted vmcnt | barrier | 16 MFMA | barrier
+// and the two wave rows run one barrier apart, so the wave that shares a SIMD with an MFMA-ing
+// wave is the one doing LDS reads and prefetch.  Prefetch order and distance: phase 1 of tile t
+// issues B1(t+1), phase 2 A1(t+1), phase 3 A0(t+2), phase 4 B0(t+2): four half-tiles (8 DMA
+// instructions per wave) stay in flight across the barriers, hence vmcnt(8); never 0 in the loop.
+// Hazards (with the stagger): a half-tile is read one phase AFTER the phase whose vmcnt retired it
+// (every wave waits for its own DMA, then a barrier), and a slot is refilled at least two phases
+// after the phase that last read it (A0: read ph.1 -> refilled ph.3; B0: ph.1 -> ph.4, B0 stays
+// in registers for the last quadrant; B1: ph.2 -> ph.1 of the next tile; A1: ph.3 -> ph.2).
+constexpr int kHalfSlot = 128 * BK;          // halfs per half-tile slot
+enum { SLOT_A0 = 0, SLOT_A1 = 1, SLOT_B0 = 2, SLOT_B1 = 3 };
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) f16 lds[];   // [2 K-tiles][4 half-tiles][128][64], the only LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int nt_n = (p.N + 255) / 256;
+    const int nt_m = (p.M + 255) / 256;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * nt_n;
+    const int group = bid / per_group;
+    const int gm0 = group * GROUP_M;
+    const int gsz = min(GROUP_M, nt_m - gm0);
+    const int in_group = bid - group * per_group;
+    const int m0 = (gm0 + in_group % gsz) * 256, n0 = (in_group / gsz) * 256;
+
+    // per-lane DMA sources: instruction i of a half-tile fills slot rows (wave*2+i)*8 + (lane>>3)
+    const f16* a_src[2][2];
+    const f16* b_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (wave * 2 + i) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            const int m = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
+            a_src[h][i] = p.A + (long)(m / p.a_rows_per_batch) * p.a_batch_stride + (long)(m % p.a_rows_per_batch) * p.lda + chunk * 8;
+            const int n = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
+            b_src[h][i] = p.W + (long)n * p.ldw + chunk * 8;
+        }
+    auto issue = [&](int buf, int slot, const f16* const (&src)[2], int tile) {
+        f16* dst = lds + (buf * 4 + slot) * kHalfSlot + wave * 2 * 8 * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)tile * BK),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 8 * BK), 16, 0, 0);
+    };
+    // fragment addresses: row r of a slot, 16-byte chunk c -> r*64 + ((c ^ ((r>>1)&7)) << 3); the XOR term
+    // depends on fr only (all row offsets are multiples of 16)
+    const int sx = (fr >> 1) & 7;
+    const int a_off0 = (wr * 64 + fr) * BK + ((fg ^ sx) << 3);          // + j*16*BK; k-step 1: chunk ^ 4
+    const int b_off0 = (wc * 32 + fr) * BK + ((fg ^ sx) << 3);
+    half8 af[4][2], b0f[2][2], b1f[2][2];
+    auto read_a = [&](const f16* slot) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            af[j][0] = *reinterpret_cast<const half8*>(slot + a_off0 + j * 16 * BK);
+            af[j][1] = *reinterpret_cast<const half8*>(slot + (a_off0 ^ 32) + j * 16 * BK);
+        }
+    };
+    auto read_b = [&](const f16* slot, half8 (&bf)[2][2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf[i][0] = *reinterpret_cast<const half8*>(slot + b_off0 + i * 16 * BK);
+            bf[i][1] = *reinterpret_cast<const half8*>(slot + (b_off0 ^ 32) + i * 16 * BK);
+        }
+    };
+    float4v acc[4][8];   // [n subtile][m subtile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+    auto quadrant = [&](auto hac, auto hbc, half8 (&bf)[2][2]) {
+        constexpr int HA = decltype(hac)::value, HB = decltype(hbc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[HB * 2 + i][HA * 4 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[i][ks], af[j][ks], acc[HB * 2 + i][HA * 4 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // MODE 0: steady state; 1: second-to-last K-tile (nothing left to issue in phases 3, 4);
+    // 2: last K-tile (nothing to issue, the remaining DMA drains 2 -> 0)
+    auto ktile = [&](auto bufc, auto modec, int t) {
+        constexpr int BUF = decltype(bufc)::value, MODE = decltype(modec)::value;
+        const f16* cur = lds + BUF * 4 * kHalfSlot;
+        // phase 1: quadrant (0,0)
+        read_b(cur + SLOT_B0 * kHalfSlot, b0f);
+        read_a(cur + SLOT_A0 * kHalfSlot);
+        if constexpr (MODE < 2) issue(BUF ^ 1, SLOT_B1, b_src[1], t + 1);
+        wait_vm<MODE < 2 ? 8 : 2>();
+        __builtin_amdgcn_s_barrier();
+        quadrant(I0{}, I0{}, b0f);
+        __builtin_amdgcn_s_barrier();
+        // phase 2: quadrant (0,1)
+        read_b(cur + SLOT_B1 * kHalfSlot, b1f);
+        if constexpr (MODE < 2) issue(BUF ^ 1, SLOT_A1, a_src[1], t + 1);
+        wait_vm<MODE < 2 ? 8 : 0>();
+        __builtin_amdgcn_s_barrier();
+        quadrant(I0{}, I1{}, b1f);
+        __builtin_amdgcn_s_barrier();
+        // phase 3: quadrant (1,1)
+        read_a(cur + SLOT_A1 * kHalfSlot);
+        if constexpr (MODE == 0) issue(BUF, SLOT_A0, a_src[0], t + 2);
+        __builtin_amdgcn_s_barrier();
+        quadrant(I1{}, I1{}, b1f);
+        __builtin_amdgcn_s_barrier();
+        // phase 4: quadrant (1,0), B0 still in registers
+        if constexpr (MODE == 0) issue(BUF, SLOT_B0, b_src[0], t + 2);
+        if constexpr (MODE < 2) wait_vm<MODE == 0 ? 8 : 4>();
+        __builtin_amdgcn_s_barrier();
+        quadrant(I1{}, I0{}, b0f);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    const int nk = p.K / BK;                         // even and >= 2 (checked by the launcher)
+    issue(0, SLOT_A0, a_src[0], 0); issue(0, SLOT_B0, b_src[0], 0);
+    issue(0, SLOT_B1, b_src[1], 0); issue(0, SLOT_A1, a_src[1], 0);
+    issue(1, SLOT_A0, a_src[0], 1); issue(1, SLOT_B0, b_src[0], 1);
+    wait_vm<8>();                                    // A0, B0 of tile 0 have landed
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();       // second wave row runs one barrier behind
+    for (int t = 0; t < nk - 2; t += 2) {
+        ktile(I0{}, I0{}, t);
+        ktile(I1{}, I0{}, t + 1);
+    }
+    ktile(I0{}, I1{}, nk - 2);
+    ktile(I1{}, std::integral_constant<int, 2>{}, nk - 1);
+    if (wr == 0) __builtin_amdgcn_s_barrier();       // same barrier count for every wave
+    gemm_epilogue<8>(p, acc, m0, n0, wr, wc, fr, fg);
+}
+
+void launch_256(const GemmParams& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)8 * kHalfSlot * sizeof(f16);     // 128 KiB
+    static bool prepared = false;
+    if (!prepared) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        prepared = true;
+    }
+    const int nt = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    hipLaunchKernelGGL(gemm256_kernel, dim3(nt), dim3(512), lds, s, p);
+}
+
 }  // namespace
 
 void launch_gemm(const GemmParams& p, hipStream_t s) {
     // MI = 8 (256-row tile, one workgroup per CU) measured 35 % slower than MI = 4 (two per CU): with a
     // single barrier-synchronised workgroup on a CU nothing covers its waits.
+    static const bool no256 = getenv("MW_GEMM_NO256") != nullptr;
+    const int nk = p.K / BK;
+    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (p.K % BK != 0) launch_t<4, false>(p, s);
+    else if (!no256 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256) launch_256(p, s);
     else launch_t<4, true>(p, s);
 }
 

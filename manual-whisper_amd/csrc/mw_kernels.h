@@ -93,7 +93,13 @@ struct GemvParams {
     // GV_LOGITS
     const uint8_t* mask_first; const uint8_t* mask_rest;
     float* part_val; int* part_idx; int n_parts;   // [B][n_parts]
+    // GV_RESID, optional: scratch of the split-K form (partial tiles + one ticket per row group; the
+    // tickets must be zero before the first launch, every launch leaves them zero again)
+    float* sk_partial; long sk_partial_floats; int* sk_tickets; int sk_groups;
 };
+// floats / ints of split-K scratch that cover every residual projection of a model of width D
+inline long splitk_partial_floats(int D) { return (long)(D / 16) * 8 * 2 * 256; }
+inline int splitk_groups(int D) { return D / 16; }
 void launch_gemv(const GemvParams& p, hipStream_t s);
 int gemv_logits_parts(int N);
 // raise the dynamic-LDS limit of every decode kernel instantiation once (not legal inside stream capture)

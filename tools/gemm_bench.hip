@@ -1,0 +1,83 @@
+// Developer harness: checks launch_gemm against a naive GPU product on random fp16 data and times it.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I manual-whisper_amd/csrc tools/gemm_bench.hip \
+//         manual-whisper_amd/csrc/kernels_gemm.o -o tools/gemm_bench
+//   tools/gemm_bench M N K [iters]
+#include "mw_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+using namespace mw;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+__global__ void fill_kernel(f16* x, long n, unsigned seed, float scale) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned h = (unsigned)i ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    x[i] = (f16)(((h >> 8) * (1.0f / 16777216.0f) - 0.5f) * 2.0f * scale);
+}
+
+__global__ void ref_kernel(const f16* A, const f16* W, const float* bias, float* C, int M, int N, int K, const int* rows, int nrows) {
+    const int r = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows || n >= N) return;
+    const int m = rows[r];
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += (float)A[(long)m * K + k] * (float)W[(long)n * K + k];
+    C[(long)r * N + n] = s + bias[n];
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 24000, N = argc > 2 ? atoi(argv[2]) : 1280, K = argc > 3 ? atoi(argv[3]) : 1280;
+    const int iters = argc > 4 ? atoi(argv[4]) : 20;
+    f16 *A, *W, *C; float *bias, *Cref; int* rows_d;
+    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 2));
+    CK(hipMalloc(&bias, (size_t)N * 4));
+    fill_kernel<<<(unsigned)(((long)M * K + 255) / 256), 256>>>(A, (long)M * K, 1u, 1.0f);
+    fill_kernel<<<(unsigned)(((long)N * K + 255) / 256), 256>>>(W, (long)N * K, 2u, 0.05f);
+    std::vector<float> hb(N);
+    for (int i = 0; i < N; ++i) hb[i] = 0.01f * (i % 17);
+    CK(hipMemcpy(bias, hb.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(C, 0xff, (size_t)M * N * 2));
+    GemmParams p{};
+    p.A = A; p.lda = K; p.a_rows_per_batch = M; p.a_batch_stride = 0; p.W = W; p.ldw = K; p.M = M; p.N = N; p.K = K;
+    p.bias = bias; p.scale = 1.f; p.scale_ncols = 0; p.gelu = 0; p.out_mode = OUT_F16; p.C = C; p.ldc = N;
+    p.c_rows_per_batch = M; p.c_batch_stride = 0;
+    hipStream_t s; CK(hipStreamCreate(&s));
+    launch_gemm(p, s);
+    CK(hipStreamSynchronize(s));
+    // reference on a spread of rows (first, last, tile edges, random)
+    std::vector<int> rows;
+    for (int m : {0, 1, 63, 64, 127, 128, 255, 256, 257, M / 2, M - 257, M - 256, M - 129, M - 2, M - 1}) if (m >= 0 && m < M) rows.push_back(m);
+    for (int i = 0; i < 113; ++i) rows.push_back((int)((1103515245u * (unsigned)(i + 7) + 12345u) % (unsigned)M));
+    const int nrows = (int)rows.size();
+    CK(hipMalloc(&rows_d, nrows * 4)); CK(hipMalloc(&Cref, (size_t)nrows * N * 4));
+    CK(hipMemcpy(rows_d, rows.data(), nrows * 4, hipMemcpyHostToDevice));
+    ref_kernel<<<dim3((N + 127) / 128, nrows), 128>>>(A, W, bias, Cref, M, N, K, rows_d, nrows);
+    std::vector<float> href((size_t)nrows * N);
+    std::vector<f16> hc((size_t)M * N);
+    CK(hipMemcpy(href.data(), Cref, href.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hc.data(), C, hc.size() * 2, hipMemcpyDeviceToHost));
+    double maxerr = 0, maxref = 0; long bad = 0;
+    for (int r = 0; r < nrows; ++r)
+        for (int n = 0; n < N; ++n) {
+            const double ref = href[(size_t)r * N + n], got = (double)(float)hc[(size_t)rows[r] * N + n];
+            const double err = fabs(ref - got);
+            if (!(err <= 2e-3 * fabs(ref) + 2e-3)) { if (bad < 5) printf("  mismatch m=%d n=%d ref=%f got=%f\n", rows[r], n, ref, got); ++bad; }
+            maxerr = fmax(maxerr, err); maxref = fmax(maxref, fabs(ref));
+        }
+    printf("check: %d rows x %d cols, max |err| %.5f (max |ref| %.3f), mismatches %ld\n", nrows, N, maxerr, maxref, bad);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_gemm(p, s);
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) launch_gemm(p, s);
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= iters;
+    printf("M=%d N=%d K=%d: %.1f us, %.1f TFLOP/s\n", M, N, K, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
+    return bad ? 2 : 0;
+}
