@@ -37,14 +37,16 @@ __device__ __forceinline__ float half_wave_sum(float v) {      // over the 32 la
 // out[b][n] = epi( sum_k X[b][k] * W[n][k] ),  b < B <= 16*MT.
 //
 // Workgroup = NW waves that split K (wave w takes k-steps w, w+NW, ...; KPW of them, compile
-// time); it owns `nv` (8 or 16) weight rows, so narrow outputs still spread over >= 160
-// workgroups (with nv = 8 lanes 8..15 of each fragment re-read rows 0..7 from L1).  Weight
+// time); it owns `nv` weight rows in R tiles of 16: nv = 8 so that narrow outputs still spread over
+// >= 160 workgroups (lanes 8..15 of each fragment re-read rows 0..7 from L1), 16 by default, and
+// 17..32 (R = 2, the second tile partly duplicates) when 16 rows would need more than one
+// workgroup per CU: past 256 workgroups a launch costs ~2.4 us more.  Weight
 // fragments go straight from global memory to the MFMA A operand; the activation fragment is the
 // B operand.  Plain input: fp16 activations, fetched with the weights.  LN input (XV > 0): the
 // fp32 residual rows are loaded once (32 lanes per row, XV float4 per lane), normalised in
 // registers (two-pass statistics, eps 1e-5) and staged in LDS as fp16 for all waves.
 // Partial sums of the waves are combined through LDS in a fixed order: bit-for-bit reproducible.
-template <int MT, int KPW, int XV>
+template <int MT, int KPW, int XV, int R>
 __global__ void gemv_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,27 +54,49 @@ __global__ void gemv_kernel(GemvParams p) {
     const int fr = lane & 15, fg = lane >> 4;
     const int nv = p.nv;
     const int n0 = blockIdx.x * nv;
-    int wrow = n0 + (nv == 16 ? fr : (fr & 7));
-    wrow = min(wrow, p.N - 1);
-    const f16* wp = p.W + (long)wrow * p.K + fg * 8;
+    const f16* wp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int local = nv == 8 ? (fr & 7) : min(r * 16 + fr, nv - 1);
+        wp[r] = p.W + (long)min(n0 + local, p.N - 1) * p.K + fg * 8;
+    }
     const int nks = p.K >> 5;
 
-    float4v* red = reinterpret_cast<float4v*>(smem);                       // [NW][MT][64]
-    char* after_red = smem + (size_t)NW * MT * 64 * 16;
+    float4v* red = reinterpret_cast<float4v*>(smem);                       // [NW][R][MT][64]
+    char* after_red = smem + (size_t)NW * R * MT * 64 * 16;
 
-    // ---- every global load of this workgroup is issued here
-    uint4 wreg[KPW];
+    // ---- every global load of this workgroup is issued here.  Loads return in issue order, so the
+    // LayerNorm operands (cache hits) go first: the normalisation then runs while the weight
+    // stream is still in flight instead of queueing behind it.
+    // Fused form: 512 threads, K = 128 * XV (the launcher guarantees both); 32 lanes per row, 16 rows per pass.
+    constexpr int XVN = XV > 0 ? XV : 1;
+    float4 v[MT][XVN];
+    float4 g4 = make_float4(0, 0, 0, 0), b4 = g4;
+    const int l32 = tid & 31;
+    const int gi = min(tid * 4, p.K - 4);       // 512 threads x 4 >= K; the surplus threads duplicate the last chunk
+    if constexpr (XV > 0) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const float* xr = p.x32 + (long)min(t * 16 + (tid >> 5), p.B - 1) * p.K + l32 * 4;   // rows >= B: duplicates
+#pragma unroll
+            for (int j = 0; j < XV; ++j) v[t][j] = *reinterpret_cast<const float4*>(xr + 128 * j);
+        }
+        g4 = *reinterpret_cast<const float4*>(p.ln_g + gi);
+        b4 = *reinterpret_cast<const float4*>(p.ln_b + gi);
+    }
+    uint4 wreg[R][KPW];
     bool kval[KPW];
 #pragma unroll
     for (int c = 0; c < KPW; ++c) {
         const int ks = wave + NW * c;
         kval[c] = ks < nks;
-        wreg[c] = *reinterpret_cast<const uint4*>(wp + min(ks, nks - 1) * 32);
+#pragma unroll
+        for (int r = 0; r < R; ++r) wreg[r][c] = *reinterpret_cast<const uint4*>(wp[r] + min(ks, nks - 1) * 32);
     }
-    // epilogue operands
-    const int nl = 4 * fg;
+    // epilogue operands: wave r finishes row tile r
+    const int nl = wave * 16 + 4 * fg;
     const int n = n0 + nl;
-    const bool owner = wave == 0 && nl < nv && n < p.N;                    // N is a multiple of 4
+    const bool owner = wave < R && nl < nv && n < p.N;                     // N and nv are multiples of 4
     float4 bias4 = make_float4(0, 0, 0, 0);
     float4 res4[MT];
     if (owner) {
@@ -93,57 +117,37 @@ __global__ void gemv_kernel(GemvParams p) {
             for (int c = 0; c < KPW; ++c) xfrag[t][c] = *reinterpret_cast<const half8*>(xr + min(wave + NW * c, nks - 1) * 32);
         }
     } else {
-        // LayerNorm of the fp32 rows: 32 lanes per row, NW*2 rows per pass
+        // LayerNorm of the fp32 rows, two-pass statistics in registers
         float* gam = reinterpret_cast<float*>(after_red);                  // [K]
         float* bet = gam + p.K;                                            // [K]
         f16* xs = reinterpret_cast<f16*>(bet + p.K);                       // [16*MT][K+8]
         const int ldx = p.K + 8;
-        const int rows_per_pass = NW * 2;
-        const int l32 = tid & 31;
-        float4 v[XV];
-        auto load_rows = [&](int r0) {          // clamped addresses: no branch around any load
-            const float* xr = p.x32 + (long)min(r0 + (tid >> 5), p.B - 1) * p.K;
-#pragma unroll
-            for (int j = 0; j < XV; ++j) v[j] = *reinterpret_cast<const float4*>(xr + min(l32 * 4 + 128 * j, p.K - 4));
-        };
-        const int gi = min(tid * 4, p.K - 4);   // 512 threads x 4 >= K for every fused width
-        const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + gi);
-        const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b + gi);
-        load_rows(0);
         *reinterpret_cast<float4*>(gam + gi) = g4;
         *reinterpret_cast<float4*>(bet + gi) = b4;
         __syncthreads();
-        for (int r0 = 0; r0 < 16 * MT; r0 += rows_per_pass) {
-            const int r = r0 + (tid >> 5);
-            if (r0 > 0) load_rows(r0);
+        const float inv_k = 1.0f / (128 * XV);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int r = t * 16 + (tid >> 5);
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < XV; ++j) {
-                if (l32 * 4 + 128 * j >= p.K) v[j] = make_float4(0, 0, 0, 0);
-                s += v[j].x + v[j].y + v[j].z + v[j].w;
-            }
-            const float mean = half_wave_sum(s) / p.K;
+            for (int j = 0; j < XV; ++j) s += (v[t][j].x + v[t][j].y) + (v[t][j].z + v[t][j].w);
+            const float mean = half_wave_sum(s) * inv_k;
             float q = 0.f;
 #pragma unroll
             for (int j = 0; j < XV; ++j) {
-                if (l32 * 4 + 128 * j < p.K) {
-                    v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
-                    q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
-                }
+                v[t][j].x -= mean; v[t][j].y -= mean; v[t][j].z -= mean; v[t][j].w -= mean;
+                q += (v[t][j].x * v[t][j].x + v[t][j].y * v[t][j].y) + (v[t][j].z * v[t][j].z + v[t][j].w * v[t][j].w);
             }
-            const float rstd = rsqrtf(half_wave_sum(q) / p.K + 1e-5f);
-            if (r < 16 * MT) {
+            const float rstd = rsqrtf(half_wave_sum(q) * inv_k + 1e-5f);
 #pragma unroll
-                for (int j = 0; j < XV; ++j) {
-                    const int c = l32 * 4 + 128 * j;
-                    if (c < p.K) {
-                        const float4 g = *reinterpret_cast<const float4*>(gam + c);
-                        const float4 b = *reinterpret_cast<const float4*>(bet + c);
-                        *reinterpret_cast<half4*>(xs + r * ldx + c) =
-                            half4{(f16)(v[j].x * rstd * g.x + b.x), (f16)(v[j].y * rstd * g.y + b.y),
-                                  (f16)(v[j].z * rstd * g.z + b.z), (f16)(v[j].w * rstd * g.w + b.w)};
-                    }
-                }
+            for (int j = 0; j < XV; ++j) {
+                const int c = l32 * 4 + 128 * j;
+                const float4 g = *reinterpret_cast<const float4*>(gam + c);
+                const float4 b = *reinterpret_cast<const float4*>(bet + c);
+                *reinterpret_cast<half4*>(xs + r * ldx + c) =
+                    half4{(f16)(v[t][j].x * rstd * g.x + b.x), (f16)(v[t][j].y * rstd * g.y + b.y),
+                          (f16)(v[t][j].z * rstd * g.z + b.z), (f16)(v[t][j].w * rstd * g.w + b.w)};
             }
         }
         __syncthreads();
@@ -154,19 +158,28 @@ __global__ void gemv_kernel(GemvParams p) {
                 xfrag[t][c] = *reinterpret_cast<const half8*>(xs + (t * 16 + fr) * ldx + min(wave + NW * c, nks - 1) * 32 + fg * 8);
     }
 
-    float4v acc[MT];
+    float4v acc[R][MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = float4v{0, 0, 0, 0};
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[r][t] = float4v{0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < KPW; ++c) {
-        uint4 w = wreg[c];
-        if (!kval[c]) w = make_uint4(0, 0, 0, 0);
+        // a k-step past the end is cancelled on the ACTIVATION side: a select on the weight register would
+        // make everything scheduled before it wait for the weight stream
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&w), xfrag[t][c], acc[t], 0, 0, 0);
+        for (int t = 0; t < MT; ++t) {
+            half8 xf = xfrag[t][c];
+            if (!kval[c]) xf = half8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wreg[r][c]), xf, acc[r][t], 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int t = 0; t < MT; ++t) red[(wave * MT + t) * 64 + lane] = acc[t];
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) red[((wave * R + r) * MT + t) * 64 + lane] = acc[r][t];
     __syncthreads();
     if (!owner) return;
 
@@ -177,7 +190,7 @@ __global__ void gemv_kernel(GemvParams p) {
         const int m = t * 16 + fr;
         if (m >= p.B) continue;
         float4v v = {bias4.x, bias4.y, bias4.z, bias4.w};
-        for (int w = 0; w < NW; ++w) v += red[(w * MT + t) * 64 + lane];
+        for (int w = 0; w < NW; ++w) v += red[((w * R + wave) * MT + t) * 64 + lane];
         if (n < p.scale_ncols) v *= p.scale;
         if (p.gelu) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
         if (p.out_mode == GV_RESID) {
@@ -260,12 +273,12 @@ __global__ __launch_bounds__(kSplitKWaves * 64) void gemv_splitk_kernel(GemvPara
 #pragma unroll
     for (int c = 0; c < KPW; ++c) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            uint4 w = wreg[r][c];
-            if (!kval[c]) w = make_uint4(0, 0, 0, 0);
+        for (int t = 0; t < MT; ++t) {
+            half8 xf = xfrag[t][c];
+            if (!kval[c]) xf = half8{0, 0, 0, 0, 0, 0, 0, 0};           // cancel on the activation side (see gemv_kernel)
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
-                acc[r * MT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&w), xfrag[t][c], acc[r * MT + t], 0, 0, 0);
+            for (int r = 0; r < R; ++r)
+                acc[r * MT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wreg[r][c]), xf, acc[r * MT + t], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -626,18 +639,27 @@ __global__ __launch_bounds__(256) void dec_finalize_kernel(FinalizeParams p, int
     }
 }
 
+template <int MT, int KPW, int XV, int R>
+void launch_gemv_r(const GemvParams& p, int nw, hipStream_t s) {
+    size_t lds = (size_t)nw * R * MT * 64 * 16;
+    if (XV > 0) lds += (size_t)2 * p.K * 4 + (size_t)16 * MT * (p.K + 8) * 2;
+    hipLaunchKernelGGL((gemv_kernel<MT, KPW, XV, R>), dim3((p.N + p.nv - 1) / p.nv), dim3(nw * 64), lds, s, p);
+}
 template <int MT, int KPW, int XV>
 void launch_gemv_t(const GemvParams& p, int nw, hipStream_t s) {
-    size_t lds = (size_t)nw * MT * 64 * 16;
-    if (XV > 0) lds += (size_t)2 * p.K * 4 + (size_t)16 * MT * (p.K + 8) * 2;
-    hipLaunchKernelGGL((gemv_kernel<MT, KPW, XV>), dim3((p.N + p.nv - 1) / p.nv), dim3(nw * 64), lds, s, p);
+    if constexpr (XV > 0) {                 // two row tiles exist for the fused kernels only (the MLP's first matrix)
+        if (p.nv > 16) { launch_gemv_r<MT, KPW, XV, 2>(p, nw, s); return; }
+    }
+    launch_gemv_r<MT, KPW, XV, 1>(p, nw, s);
 }
 
 constexpr int kMaxLds = 160 * 1024;
 
 template <int MT, int KPW, int XV>
 void prepare_gemv_t() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<MT, KPW, XV>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<MT, KPW, XV, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    if constexpr (XV > 0)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<MT, KPW, XV, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
 }
 template <int MT>
 void prepare_mt() {
@@ -665,6 +687,7 @@ bool launch_gemv_mt(const GemvParams& p, hipStream_t s) {
         launch_layernorm(p.x32, p.ln_g, p.ln_b, p.ln_scratch, nullptr, p.B, p.K, s);
         GemvParams q = p;
         q.ln_g = nullptr; q.ln_b = nullptr; q.xin16 = p.ln_scratch;
+        if (q.nv > 16) q.nv = 16;               // the plain form has one row tile
         return launch_gemv_mt<MT>(q, s);
     }
     const int nw = nks >= 48 ? 16 : nks >= 16 ? 8 : 4;
@@ -731,6 +754,8 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
     static const int nv_narrow = getenv("MW_NV_NARROW") ? atoi(getenv("MW_NV_NARROW")) : 8;
     static const int nv_wide = getenv("MW_NV_WIDE") ? atoi(getenv("MW_NV_WIDE")) : 16;
     p.nv = p.N <= 2048 ? nv_narrow : nv_wide;
+    if (p.ln_g && p.nv == 16 && p.N > 256 * 16 && p.N <= 256 * 32)        // at most one workgroup per CU
+        p.nv = ((p.N + 255) / 256 + 3) / 4 * 4;
     if (p.out_mode == GV_RESID && !p.ln_g && launch_splitk(p, mt, s)) return;
     if (mt == 1) (void)launch_gemv_mt<1>(p, s); else (void)launch_gemv_mt<2>(p, s);
 }
