@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Development aid: from a rocprofv3 results database (kernel trace), report how much of the traced span
+had 0, 1, 2, 3+ kernels executing, overall and for the span of the timed steps.
+Usage: python tools/overlap_stats.py results.db"""
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+rows = db.execute("select start, end, stream_id, name from kernels where name like '%mw::%' or name like '%_ZN2mw%' order by start").fetchall()
+ev = []
+for s, e, _, _ in rows:
+    ev.append((s, 1))
+    ev.append((e, -1))
+ev.sort()
+hist = {}
+cur, last = 0, ev[0][0]
+for t, d in ev:
+    hist[min(cur, 4)] = hist.get(min(cur, 4), 0) + (t - last)
+    cur += d
+    last = t
+span = ev[-1][0] - ev[0][0]
+print(f"engine kernels: {len(rows)}, span {span / 1e6:.1f} ms")
+for k in sorted(hist):
+    print(f"  {k}{'+' if k == 4 else ' '} kernels in flight: {hist[k] / 1e6:9.1f} ms  {100.0 * hist[k] / span:5.1f} %")
+streams = {}
+for s, e, sid, _ in rows:
+    streams.setdefault(sid, []).append((s, e))
+for sid, iv in streams.items():
+    busy = sum(e - s for s, e in iv)
+    print(f"  stream {sid}: {len(iv)} kernels, busy {busy / 1e6:.1f} ms over {(iv[-1][1] - iv[0][0]) / 1e6:.1f} ms")
