@@ -120,6 +120,16 @@ int mw_decode_forced(mw_ctx* ctx, int batch, const int32_t* tokens, int n, float
 /* Stages 1-3 in one call: pcm float32 [batch][480000] -> ids. */
 int mw_transcribe_batch(mw_ctx* ctx, const float* pcm, int batch, int32_t* out_ids, int32_t* out_len);
 
+/* ---- the step before the path: speech-activity windows ---- */
+
+/* Frame log-energies of mono 16 kHz PCM, the input of the window search that stands where whisperx
+ * runs its VAD before cutting <= 30 s windows (the reference passes vad_options to it:
+ * transcribe.py:43-46,112; the thresholds and the window merge live on the host side).
+ *   out_db[f] = 10*log10( mean of x[f*hop + i]^2 over i < frame that exist + 1e-10 ),
+ *   f < n_frames, and n_frames must equal ceil(n_samples / hop).
+ * pcm: float32 [n_samples], host or device memory.  out_db: float32 [n_frames], host or device. */
+int mw_frame_energy_db(mw_ctx* ctx, const float* pcm, int64_t n_samples, int frame, int hop, float* out_db, int64_t n_frames);
+
 /* ---- measurement ---- */
 
 /* GPU time in ms of the last call's stages, from HIP events on the context's stream:

@@ -61,11 +61,10 @@ def transcribe_audio(audio_file, hf_token=None):
         import torch
         import torch.distributed as dist
         from .parallel import transcribe_sharded
-        from .scheduler import split_chunks
         if not dist.is_initialized():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        chunks, spans = split_chunks(audio)
+        chunks, spans = model.windows(audio)
         ids = transcribe_sharded(lambda c: model.transcribe_ids_chunks(c, BATCH_SIZE, "zh"), chunks, model.max_new,
                                  device=torch.device("cuda", local_rank))
         result = {"segments": [{"text": model.detokenize(i), "start": round(a, 3), "end": round(b, 3)}
@@ -76,7 +75,7 @@ def transcribe_audio(audio_file, hf_token=None):
             seg.pop("tokens", None)
     dt = time.time() - t
     say(f"   转写耗时: {dt:.1f}s (实时比: {dt/max(audio_duration, 1e-9):.3f}x, {audio_duration/max(dt, 1e-9):.0f} audio-s/s)")
-    say("⚠️ 时间戳对齐与说话人分离不在本引擎范围内：片段时间为 30 秒分块边界。")
+    say("⚠️ 时间戳对齐与说话人分离不在本引擎范围内：片段时间为语音活动窗口（≤30 秒）的边界。")
     model.close()
     say("🧹 清理转写文本...")
     kept, changed, dropped = postprocess.clean_segments(result.get("segments", []))

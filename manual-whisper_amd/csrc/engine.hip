@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <set>
 #include <string>
@@ -866,6 +867,47 @@ extern "C" int mw_transcribe_batch(mw_ctx* ctx, const float* pcm, int batch, int
     HIPCHK(hipMemcpyAsync(out_len, ctx->out_len, (size_t)batch * 4, hipMemcpyDefault, s));
     HIPCHK(hipStreamSynchronize(s));
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+    return MW_OK;
+}
+
+extern "C" int mw_frame_energy_db(mw_ctx* ctx, const float* pcm, int64_t n_samples, int frame, int hop, float* out_db,
+                                  int64_t n_frames) {
+    if (!ctx) return MW_ERR_ARG;
+    if (!pcm || !out_db) return fail(ctx, MW_ERR_ARG, "mw_frame_energy_db: null pointer");
+    if (n_samples < 1 || hop < 1 || frame < hop || frame > (1 << 20))
+        return fail(ctx, MW_ERR_ARG, "mw_frame_energy_db: need n_samples >= 1 and 1 <= hop <= frame <= 2^20");
+    if (n_frames != (n_samples + hop - 1) / hop)
+        return fail(ctx, MW_ERR_ARG, "mw_frame_energy_db: n_frames must be ceil(n_samples / hop)");
+    HIPCHK(hipSetDevice(ctx->device));
+    const bool pcm_dev = is_device_ptr(pcm), out_dev = is_device_ptr(out_db);
+    float* d_out = out_db;
+    if (!out_dev) HIPCHK(hipMalloc(&d_out, (size_t)n_frames * 4));
+    int rc = MW_OK;
+    if (pcm_dev) {
+        launch_frame_energy(pcm, n_samples, frame, hop, d_out, n_frames, ctx->stream);
+    } else {
+        // host audio: staged in pieces of whole hops, each with the (frame - hop) samples its last frames reach into
+        const int64_t piece_frames = (int64_t)(1 << 24) / hop;                      // ~16 M samples per piece
+        const int64_t cap = piece_frames * hop + frame;
+        float* d_pcm = nullptr;
+        hipError_t e = hipMalloc(&d_pcm, (size_t)std::min<int64_t>(cap, n_samples) * 4);
+        if (e != hipSuccess) { if (!out_dev) (void)hipFree(d_out); return fail(ctx, MW_ERR_HIP, "mw_frame_energy_db: out of device memory"); }
+        for (int64_t f0 = 0; f0 < n_frames && rc == MW_OK; f0 += piece_frames) {
+            const int64_t nf = std::min<int64_t>(piece_frames, n_frames - f0);
+            const int64_t s0 = f0 * hop;
+            const int64_t ns = std::min<int64_t>(n_samples - s0, (nf - 1) * hop + frame);
+            if (hipMemcpyAsync(d_pcm, pcm + s0, (size_t)ns * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = MW_ERR_HIP; break; }
+            // the piece is its own signal of ns samples, except that only its first nf frames are wanted
+            launch_frame_energy(d_pcm, ns, frame, hop, d_out + f0, nf, ctx->stream);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = MW_ERR_HIP;   // d_pcm is reused by the next piece
+        }
+        (void)hipFree(d_pcm);
+    }
+    if (rc == MW_OK && hipGetLastError() != hipSuccess) rc = MW_ERR_HIP;
+    if (rc == MW_OK && !out_dev && hipMemcpyAsync(out_db, d_out, (size_t)n_frames * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = MW_ERR_HIP;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = MW_ERR_HIP;
+    if (!out_dev) (void)hipFree(d_out);
+    if (rc != MW_OK) return fail(ctx, rc, "mw_frame_energy_db: HIP error");
     return MW_OK;
 }
 

@@ -33,6 +33,9 @@ void launch_mel_norm(float* logmel, const float* blockmax, int B, int n_mels, f1
 // float32 features supplied by the caller -> melT
 void launch_mel_import(const float* mel, int B, int n_mels, f16* melT, hipStream_t s);
 
+// frame log-energies (dB) of mono PCM: out[f] over samples [f*hop, f*hop+frame) that exist, f < n_frames = ceil(n/hop)
+void launch_frame_energy(const float* pcm, long n, int frame, int hop, float* out, long n_frames, hipStream_t s);
+
 // ---------------------------------------------------------------- big GEMM (encoder, cross K/V)
 enum GemmOut { OUT_F16 = 0, OUT_RESID_F32 = 1, OUT_QKV_SPLIT = 2, OUT_KV_SPLIT = 3 };
 struct GemmParams {

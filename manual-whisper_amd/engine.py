@@ -129,6 +129,23 @@ class Engine:
         self._check(self._lib.mw_logmel(self._h, _ptr(pcm), B, _ptr(out) if want_output else None), "mw_logmel")
         return out
 
+    def frame_energy_db(self, audio, frame: int = 400, hop: int = 160) -> np.ndarray:
+        """Frame log-energies (dB) of a whole recording: float32 [n] (numpy, or a tensor on this GPU)
+        -> float32 [ceil(n / hop)].  Input of the speech-activity window search (vad.py)."""
+        if isinstance(audio, np.ndarray):
+            audio = np.ascontiguousarray(audio, dtype=np.float32).reshape(-1)
+            n = int(audio.shape[0])
+        else:
+            if str(audio.dtype) != "torch.float32" or audio.dim() != 1 or not audio.is_contiguous():
+                raise EngineError("audio tensor must be contiguous float32 [n]")
+            n = int(audio.shape[0])
+        if n == 0:
+            return np.zeros(0, np.float32)
+        n_frames = (n + hop - 1) // hop
+        out = np.empty(n_frames, np.float32)
+        self._check(self._lib.mw_frame_energy_db(self._h, _ptr(audio), n, frame, hop, _ptr(out), n_frames), "mw_frame_energy_db")
+        return out
+
     def encode(self, batch: int, mel: Optional[np.ndarray] = None, want_output: bool = True) -> Optional[np.ndarray]:
         if mel is not None:
             mel = np.ascontiguousarray(mel, dtype=np.float32)

@@ -9,7 +9,10 @@ Differences that cannot be avoided offline, all stated where they bite:
   * weights come from a LOCAL directory in Hugging Face layout (config.json + model.safetensors or
     pytorch_model.bin [+ tokenizer.json]); nothing is downloaded.  ``synthetic:<size>`` builds the
     deterministic random-init checkpoint used by the tests and the benchmark.
-  * windows are fixed 30 s chunks; ``vad_options`` is accepted and recorded but no VAD model runs.
+  * windows: with ``vad_options`` (as the reference passes them) the recording is cut into speech
+    windows of at most 30 s by vad.py (energy detector + whisperx's hysteresis / merge rules; the
+    neural VAD model does not exist offline); ``vad_options=None`` or ``{"vad_method": "fixed"}``
+    gives fixed 30 s chunks.
   * decoding is greedy without timestamps; text needs tokenizer.json, otherwise a segment's text is
     its token ids written as ``<|id|>`` and the ids are also returned under ``"tokens"``.
 """
@@ -80,6 +83,17 @@ class Model:
             return self.tokenizer.decode(ids, skip_special_tokens=True)
         return "".join(f"<|{i}|>" for i in ids)
 
+    # -- windows ------------------------------------------------------------------------
+    def uses_vad(self) -> bool:
+        return bool(self.vad_options) and self.vad_options.get("vad_method", "energy") != "fixed"
+
+    def windows(self, audio: np.ndarray):
+        """Recording -> ([n, 480000] chunks, [(start_s, end_s)]): speech windows, or fixed 30 s chunks."""
+        if not self.uses_vad():
+            return split_chunks(audio)
+        from . import vad
+        return vad.cut_windows(audio, vad.speech_windows(self.engine, audio, self.vad_options))
+
     # -- the hot path -------------------------------------------------------------------
     def transcribe_ids(self, audio: np.ndarray, batch_size: int = 16, language: Optional[str] = None):
         """-> (chunk spans [(start, end)], list of id arrays), no text handling."""
@@ -87,7 +101,7 @@ class Model:
         if self._opts_for != language:
             self.pool.set_decode_options(self.decode_options(language))
             self._opts_for = language
-        chunks, spans = split_chunks(audio)
+        chunks, spans = self.windows(audio)
         return spans, self.transcribe_ids_chunks(chunks, batch_size, language)
 
     def transcribe_ids_chunks(self, chunks: np.ndarray, batch_size: int = 16, language: Optional[str] = None):

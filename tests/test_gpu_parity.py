@@ -274,14 +274,19 @@ def test_forks_share_weights_and_run_concurrently(micro):
 
 
 def test_cli_end_to_end(tmp_path):
-    """`python transcribe.py x.wav` with a synthetic checkpoint: files appear, segments are the 30 s
-    chunk spans, and ids equal Model.transcribe_ids on the same audio."""
+    """`python transcribe.py x.wav` with a synthetic checkpoint: files appear, segments are the speech
+    windows (the CLI passes the reference's VAD_OPTIONS), and ids equal Model.transcribe_ids on the
+    same audio."""
     import json
     import subprocess
     import sys
     from manual_whisper_amd import audio as aud
+    from manual_whisper_amd import cli
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    x = synth.make_pcm_np(3, seed=71).reshape(-1)[: 16000 * 70]          # 70 s -> 3 chunks, last one padded
+    sr = 16000
+    x = synth.make_pcm_np(3, seed=71).reshape(-1)[: sr * 70].copy()      # 70 s: speech 0-25 s, silence, speech 40-65 s, silence
+    x[25 * sr: 40 * sr] = 0.0
+    x[65 * sr:] = 0.0
     wav = tmp_path / "meeting.wav"
     aud.write_wav(str(wav), x)
     env = dict(os.environ, WHISPER_MODEL="synthetic:micro", BATCH_SIZE="2", MW_ENGINES="2")
@@ -290,11 +295,16 @@ def test_cli_end_to_end(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     md = (tmp_path / "meeting_transcript.md").read_text(encoding="utf-8")
     js = json.loads((tmp_path / "meeting_transcript.json").read_text(encoding="utf-8"))
-    assert md.startswith("# 会议录音转写") and "[00:00:00 - 00:00:30]" in md and "[00:01:00 - 00:01:10]" in md
-    assert [s["start"] for s in js["segments"]] == [0.0, 30.0, 60.0] and js["segments"][2]["end"] == 70.0
-    model = mw.load_model("synthetic:micro", "cuda", max_batch=2, n_engines=1)
+    import re
+    assert md.startswith("# 会议录音转写") and len(re.findall(r"\[\d\d:\d\d:\d\d - \d\d:\d\d:\d\d\]", md)) == 2
+    got_spans = [(s["start"], s["end"]) for s in js["segments"]]
+    assert len(got_spans) == 2
+    for (a, b), (wa, wb) in zip(got_spans, [(0.0, 25.0), (40.0, 65.0)]):
+        assert abs(a - wa) < 0.2 and abs(b - wb) < 0.2
+    model = mw.load_model("synthetic:micro", "cuda", max_batch=2, n_engines=1, vad_options=cli.VAD_OPTIONS)
     spans, ids = model.transcribe_ids(mw.load_audio(str(wav)), batch_size=2)
     model.close()
+    assert [(round(a, 3), round(b, 3)) for a, b in spans] == got_spans
     from manual_whisper_amd.postprocess import clean_segment_text
     for seg, t in zip(js["segments"], ids):       # the CLI runs the reference's clean-up on every segment
         assert seg["text"] == clean_segment_text("".join(f"<|{i}|>" for i in t))
