@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Development aid for hardware-counter runs: a torch-free process (MW_SYSTEM_HIP=1, system ROCm
-runtime) that runs a few large-v3 decode steps at batch 16 on random weights.  Used as
-`rocprofv3 --pmc FETCH_SIZE -- python3 tools/pmc_probe.py` (and WRITE_SIZE in its own pass)."""
+runtime) that runs log-mel, the encoder, cross K/V and a few large-v3 decode steps at batch 16 on
+random weights.  Used as `rocprofv3 --pmc FETCH_SIZE -- python3 tools/pmc_probe.py`, with
+WRITE_SIZE and the SQ / GRBM counters each in a pass of their own; tools/pmc_summary.py turns
+the per-dispatch CSVs into one table."""
 import os, sys
 os.environ["MW_SYSTEM_HIP"] = "1"
 import numpy as np
@@ -26,8 +28,9 @@ for name, shape, kind, scale in synth.tensor_specs(dims):
 eng.load_weights(w)
 del w
 eng.set_decode_options(synthetic_options(dims, max_new=int(os.environ.get("MW_NEW", "3")), suppress_eot=True))
-mel = rng.standard_normal((B, dims.n_mels, 3000), dtype=np.float32) * 0.3
-eng.encode(B, mel=mel, want_output=False)
+pcm = synth.make_pcm_np(B, seed=7)
+eng.logmel(pcm, want_output=False)
+eng.encode(B, want_output=False)
 eng.set_option("graph", 0)
 eng.decode_greedy(B)
 print("done", eng.stage_ms())
