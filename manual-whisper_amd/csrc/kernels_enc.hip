@@ -74,14 +74,40 @@ __global__ void bcast_rows_kernel(const float* __restrict__ table, float* __rest
 //
 // S^T = K Q^T is computed with keys on the MFMA row index, so a lane holds, for ONE query
 // (column lane&15), 4 keys per 16-key tile: the running max / sum of the online softmax need only
-// the 4 lanes that share a column (two xor shuffles).  Those same registers, converted to fp16,
-// are directly the B operand of O^T = V^T P^T (k index = key) once V^T fragments are fetched
-// with the matching key permutation; V arrives already transposed ([64][T]) from the QKV GEMM, so
-// each fragment is two 8-byte LDS reads.  Output O^T has the query on the lane again, so the
-// rescale factors are per-lane scalars.
+// the 4 lanes that share a column (v_permlane16_swap + v_permlane32_swap: plain VALU, no LDS round
+// trip).  Those same registers, converted to fp16, are directly the B operand of O^T = V^T P^T
+// (k index = key).  V arrives already transposed ([64][T]) from the QKV GEMM; its tile is staged
+// with the keys permuted in groups of four so that the 8 keys a lane contracts over are contiguous:
+// every V^T fragment is one ds_read_b128, like the K fragments.  Output O^T has the query on the
+// lane again, so the rescale factors are per-lane scalars.
+//
+// Softmax arithmetic per score: one fma (score * log2e - max * log2e), one v_exp_f32, one add, one
+// max, half a convert.  The running max is only raised when some query of the wave exceeds it by
+// more than kRescaleGap (in log2 units), so the O / l rescale is skipped for almost every tile; P
+// then reaches at most 2^kRescaleGap, far inside fp16 range.
 constexpr int AQ = 128, AKV = 64;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kRescaleGap = 6.0f;
 
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+// max over the 4 lanes lane&15, +16, +32, +48 (every lane gets the result)
+__device__ __forceinline__ float quad_column_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned w = __float_as_uint(v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float quad_column_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned w = __float_as_uint(v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 __global__ __launch_bounds__(256) void enc_attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                             const f16* __restrict__ vT, f16* __restrict__ out, int H,
@@ -126,19 +152,25 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16* __restric
             rv[i] = kc < Tpad ? *reinterpret_cast<const uint4*>(vb + (long)row * Tpad + kc) : make_uint4(0, 0, 0, 0);
         }
     };
+    // V^T key permutation inside a tile: key 32s + 16h + 4g + r  ->  column 32s + 8g + 4h + r, i.e. the
+    // source chunk c (keys 8c..8c+7: s = c>>2, h = (c>>1)&1, g = 2(c&1), 2(c&1)+1) lands as two
+    // 8-byte pieces in destination chunks 4s + 2(c&1) and 4s + 2(c&1) + 1, at half-offset 4h.
+    const int vdst_chunk = (ch & 4) + 2 * (ch & 1), vdst_off = 4 * ((ch >> 1) & 1);
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (tid >> 3) + 32 * i;
             *reinterpret_cast<uint4*>(&lds[buf][0][swz64(row, ch)]) = rk[i];
-            *reinterpret_cast<uint4*>(&lds[buf][1][swz64(row, ch)]) = rv[i];
+            *reinterpret_cast<uint2*>(&lds[buf][1][swz64(row, vdst_chunk) + vdst_off]) = make_uint2(rv[i].x, rv[i].y);
+            *reinterpret_cast<uint2*>(&lds[buf][1][swz64(row, vdst_chunk + 1) + vdst_off]) = make_uint2(rv[i].z, rv[i].w);
         }
     };
 
     float4v o[4][2];           // [head-dim tile][query tile]: O^T
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[i][0] = float4v{0, 0, 0, 0}; o[i][1] = float4v{0, 0, 0, 0}; }
-    float mrun[2] = {-1.0e30f, -1.0e30f}, lrun[2] = {0.f, 0.f};
+    float mrun[2] = {-1.0e30f, -1.0e30f};      // running max in log2 units (score * log2e)
+    float lrun[2] = {0.f, 0.f};
 
     const int ntile = (T + AKV - 1) / AKV;
     gload(0);
@@ -168,48 +200,51 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16* __restric
                     if (kv0 + i * 16 + 4 * fg + r >= T) { sc[i][0][r] = -1.0e30f; sc[i][1][r] = -1.0e30f; }
         }
         // ---- online softmax per query column
+        float mx[2];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            float m = fmaxf(fmaxf(sc[0][qs][0], sc[0][qs][1]), fmaxf(sc[0][qs][2], sc[0][qs][3]));
+#pragma unroll
+            for (int i = 1; i < 4; ++i) m = fmaxf(m, fmaxf(fmaxf(sc[i][qs][0], sc[i][qs][1]), fmaxf(sc[i][qs][2], sc[i][qs][3])));
+            mx[qs] = quad_column_max(m) * kLog2e;
+        }
+        if (__any(mx[0] > mrun[0] + kRescaleGap || mx[1] > mrun[1] + kRescaleGap)) {     // wave-uniform, rare after the first tiles
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                const float mnew = fmaxf(mrun[qs], mx[qs]);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[qs] - mnew);
+                mrun[qs] = mnew;
+                lrun[qs] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { o[i][qs][0] *= alpha; o[i][qs][1] *= alpha; o[i][qs][2] *= alpha; o[i][qs][3] *= alpha; }
+            }
+        }
         half8 pf[2][2];            // [query tile][k step of 32 keys]
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
-            float mx = sc[0][qs][0];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[i][qs][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[qs], mx);
-            const float alpha = __expf(mrun[qs] - mnew);
-            mrun[qs] = mnew;
+            const float nm = -mrun[qs];
             float ps = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __expf(sc[i][qs][r] - mnew);
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[i][qs][r], kLog2e, nm));
                     sc[i][qs][r] = pv;
                     ps += pv;
                 }
-            lrun[qs] = lrun[qs] * alpha + ps;           // partial over this lane's keys; reduced at the end
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { o[i][qs][0] *= alpha; o[i][qs][1] *= alpha; o[i][qs][2] *= alpha; o[i][qs][3] *= alpha; }
+            lrun[qs] += ps;                              // partial over this lane's keys; reduced at the end
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 pf[qs][s] = half8{(f16)sc[2 * s][qs][0], (f16)sc[2 * s][qs][1], (f16)sc[2 * s][qs][2], (f16)sc[2 * s][qs][3],
                                   (f16)sc[2 * s + 1][qs][0], (f16)sc[2 * s + 1][qs][1], (f16)sc[2 * s + 1][qs][2],
                                   (f16)sc[2 * s + 1][qs][3]};
         }
-        // ---- O^T += V^T P^T ; element j of k-step s is key 32s + 16(j>>2) + 4*fg + (j&3)
+        // ---- O^T += V^T P^T ; element j of k-step s is key 32s + 16(j>>2) + 4*fg + (j&3) = permuted column 32s + 8fg + j
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const int row = dt * 16 + fr;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                // keys 32s+4fg..+3 sit in chunk 4s + (fg>>1) at half offset 4*(fg&1); +16 keys = chunk + 2
-                const int c0 = 4 * s + (fg >> 1), off = 4 * (fg & 1);
-                const half4 lo = *reinterpret_cast<const half4*>(&lds[buf][1][swz64(row, c0) + off]);
-                const half4 hi = *reinterpret_cast<const half4*>(&lds[buf][1][swz64(row, c0 + 2) + off]);
-                const half8 vf = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const half8 vf = *reinterpret_cast<const half8*>(&lds[buf][1][swz64(dt * 16 + fr, 4 * s + fg)]);
                 o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0][s], o[dt][0], 0, 0, 0);
                 o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][s], o[dt][1], 0, 0, 0);
             }
@@ -222,10 +257,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const f16* __restric
     const int b = bh / H, h = bh - b * H;
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
-        float l = lrun[qs];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
-        const float inv = 1.0f / l;
+        const float inv = 1.0f / quad_column_sum(lrun[qs]);
         const int row = q0 + qs * 16 + fr;
         if (row < T) {
             f16* dst = out + ((long)b * T + row) * (H * 64) + h * 64 + 4 * fg;
