@@ -112,3 +112,19 @@ def test_config4_long_audio_chunk_bookkeeping():
     shards = [parallel.shard_range(120, r, 8) for r in range(8)]
     assert [b - a for a, b in shards] == [15] * 8
     assert scheduler.batches_of(15, 16) == [(0, 15)]
+
+
+def test_config5_shape_large_v3_batch32():
+    """Batch 32 at full size (the per-GPU batch of the fp8 configuration, here with fp16 weights):
+    both halves decode exactly as they do alone at batch 16."""
+    dims, eng, _ = _engine_and_oracle("large-v3", 32, with_oracle=False)
+    try:
+        opts = synthetic_options(dims, max_new=12, suppress_eot=True)
+        eng.set_decode_options(opts)
+        pcm = synth.make_pcm_np(32, seed=505)
+        a, la = eng.transcribe_batch(pcm)
+        lo, _ = eng.transcribe_batch(pcm[:16])
+        hi, _ = eng.transcribe_batch(pcm[16:])
+        assert (la == 12).all() and (a[:16] == lo).all() and (a[16:] == hi).all()
+    finally:
+        eng.close()

@@ -311,3 +311,34 @@ def test_cli_end_to_end(tmp_path):
     missing = subprocess.run([sys.executable, os.path.join(root, "transcribe.py"), "nope.wav"], cwd=tmp_path, env=env,
                              capture_output=True, text=True, timeout=120)
     assert missing.returncode == 1 and "文件不存在" in missing.stdout
+
+
+@pytest.mark.parametrize("name", ["micro", "tiny"])
+def test_batches_above_16_use_the_two_tile_kernels(name):
+    """Batches of 17..32 sequences run the decode kernels with two 16-row MFMA tiles: the ids of a
+    chunk must not depend on which tile or batch it sits in, and they match the oracle."""
+    dims = mw.get_dims(name)
+    w = synth.make_weights_np(dims, 99)
+    eng = _engine(dims, w, max_batch=32)
+    try:
+        opts = synthetic_options(dims, max_new=8)
+        eng.set_decode_options(opts)
+        pcm = synth.make_pcm_np(32, seed=31)
+        ids32, lens32 = eng.transcribe_batch(pcm)
+        lo, _ = eng.transcribe_batch(pcm[:16])
+        hi, _ = eng.transcribe_batch(pcm[16:])
+        assert (ids32[:16] == lo).all() and (ids32[16:] == hi).all()
+        for n in (17, 31):
+            part, _ = eng.transcribe_batch(pcm[:n])
+            assert (part == ids32[:n]).all(), n
+        orc = WhisperOracle(dims, w)
+        sel = [0, 15, 16, 17, 31]
+        want, _ = orc.transcribe_ids(pcm[sel], list(opts.prompt), opts.max_new, opts.eot, opts.suppress, opts.begin_suppress)
+        assert_ids_match_up_to_ties(ids32[sel], want, orc.last_margins)
+        toks = np.tile(np.asarray(opts.prompt + (3, 4, 5), np.int32)[None], (32, 1))
+        mel_ref = log_mel(pcm[sel], dims.n_mels)
+        eng.transcribe_batch(pcm)                                  # leaves the encoder state of all 32 chunks
+        got = eng.decode_forced(toks)[sel]
+        assert np.abs(got - orc.forced_logits(orc.encode(mel_ref), toks[: len(sel)])).max() < LOGIT_ATOL
+    finally:
+        eng.close()
