@@ -117,6 +117,18 @@ int mw_decode_greedy(mw_ctx* ctx, int batch, int32_t* out_ids, int32_t* out_len,
  * logits_out float32 [batch][n][vocab]. */
 int mw_decode_forced(mw_ctx* ctx, int batch, const int32_t* tokens, int n, float* logits_out);
 
+/* Beam search at temperature 0 over the encoder state of the last mw_encode(n_audio): the decoding
+ * whisperx runs by default behind model.transcribe (the reference overrides only initial_prompt,
+ * transcribe.py:111,123).  n_audio * beam sequences must fit max_batch; beam in 1..8; patience in
+ * [1, 4] (finished hypotheses kept per recording = round(beam * patience)).  The winner maximises
+ * cumulative log-probability per token.
+ * out_ids int32 [n_audio][max_new] padded with eot; out_len int32 [n_audio]; out_avg_logprob
+ * float32 [n_audio] or NULL (sum / (len + 1)).  Optional (NULL to skip): every ranked hypothesis,
+ * hyp_ids int32 [n_audio][beam][max_new], hyp_len int32 [n_audio][beam] (-1 = none),
+ * hyp_sum_logprob float32 [n_audio][beam]. */
+int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience, int32_t* out_ids, int32_t* out_len,
+                   float* out_avg_logprob, int32_t* hyp_ids, int32_t* hyp_len, float* hyp_sum_logprob);
+
 /* Stages 1-3 in one call: pcm float32 [batch][480000] -> ids. */
 int mw_transcribe_batch(mw_ctx* ctx, const float* pcm, int batch, int32_t* out_ids, int32_t* out_len);
 

@@ -75,6 +75,10 @@ struct mw_ctx {
     int forced_cap = 0;
     float* xpartial = nullptr; int* xtickets = nullptr;    // cross-attention key-range partials + ticket counters
     float* skpartial = nullptr; int* sktickets = nullptr;  // split-K partial tiles + ticket counters of the residual projections
+    // beam search (allocated on first use)
+    float *bm_sum_lp = nullptr, *bm_fin_lp = nullptr;
+    int *bm_hist = nullptr, *bm_src_rows = nullptr, *bm_fin_tokens = nullptr, *bm_fin_len = nullptr, *bm_fin_count = nullptr,
+        *bm_completed = nullptr;
 
     // decode options
     std::vector<int32_t> prompt;
@@ -669,7 +673,7 @@ extern "C" int mw_encode(mw_ctx* ctx, const float* mel, int batch, float* enc_ou
 }
 
 // One greedy step: 8 launches per layer + final norm + logits + token bookkeeping.
-static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp) {
+static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, const BeamParams* beam = nullptr) {
     const mw_model_desc& d = ctx->d;
     const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, Tc = d.n_text_ctx;
     hipStream_t s = ctx->stream;
@@ -693,7 +697,7 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
             p.out_mode = GV_QKV; p.out16 = ctx->dq; p.kcache = sk; p.vcache = sv;
             launch_gemv(p, s);
         }
-        launch_dec_self_attn(ctx->dq, sk, sv, ctx->datt, B, H, Tc, ctx->st, s);
+        launch_dec_self_attn(ctx->dq, sk, sv, ctx->datt, B, H, Tc, ctx->st, s, beam ? beam->src_rows : nullptr);
         {   GemvParams p = base(D, D, l.out); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
         {   // LN2 + cross-attention query
             GemvParams p = base(D, D, l.cq);
@@ -702,7 +706,7 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
             launch_gemv(p, s);
         }
         launch_dec_cross_attn(ctx->dq, ctx->crossK + li * cross_layer, ctx->crossV + li * cross_layer, ctx->datt, B, H, T,
-                              ctx->xpartial, ctx->xtickets, s);
+                              ctx->xpartial, ctx->xtickets, s, beam ? beam->beam : 1);
         {   GemvParams p = base(D, D, l.co); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
         {   // LN3 + fc1 + GELU
             GemvParams p = base(F, D, l.fc1);
@@ -721,7 +725,8 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
         p.part_val = ctx->part_val; p.part_idx = ctx->part_idx; p.n_parts = ctx->n_parts;
         launch_gemv(p, s);
     }
-    launch_dec_finalize(fp, B, s);
+    if (beam) launch_beam_step(*beam, s);
+    else launch_dec_finalize(fp, B, s);
 }
 
 static FinalizeParams finalize_params(mw_ctx* ctx, int n_forced) {
@@ -734,12 +739,12 @@ static FinalizeParams finalize_params(mw_ctx* ctx, int n_forced) {
 }
 
 // Capture (or re-use) the graph of one step for this batch size / forced length / logits flag.
-static int ensure_graph(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int key) {
+static int ensure_graph(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int key, const BeamParams* beam = nullptr) {
     if (ctx->graph_exec && ctx->graph_batch == key && ctx->graph_logits == (int)want_logits) return MW_OK;
     if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
     if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
     HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    enqueue_step(ctx, B, want_logits, fp);
+    enqueue_step(ctx, B, want_logits, fp, beam);
     HIPCHK(hipStreamEndCapture(ctx->stream, &ctx->graph));
     HIPCHK(hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0));
     ctx->graph_batch = key; ctx->graph_logits = (int)want_logits;
@@ -806,6 +811,114 @@ extern "C" int mw_decode_greedy(mw_ctx* ctx, int batch, int32_t* out_ids, int32_
     HIPCHK(hipMemcpyAsync(out_len, ctx->out_len, (size_t)batch * 4, hipMemcpyDefault, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipEventElapsedTime(&ctx->stage_ms[3], ctx->ev[3], ctx->ev[4]));
+    return MW_OK;
+}
+
+// Beam search over the encoder state of the last mw_encode: n_audio recordings x beam hypotheses
+// run as n_audio*beam sequences through the same step kernels (cross-attention reads the cache of
+// recording r / beam, self-attention follows src_rows), bookkeeping in beam_step_kernel, the final
+// top-up and ranking on the host.
+extern "C" int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience, int32_t* out_ids, int32_t* out_len,
+                              float* out_avg_logprob, int32_t* hyp_ids, int32_t* hyp_len, float* hyp_sum_logprob) {
+    if (!ctx) return MW_ERR_ARG;
+    if (!ctx->opts_set) return fail(ctx, MW_ERR_STATE, "mw_decode_beam: call mw_set_decode_opts first");
+    if (beam < 1 || beam > kMaxBeam) return fail(ctx, MW_ERR_ARG, "mw_decode_beam: beam must be in 1.." + std::to_string(kMaxBeam));
+    if (!(patience >= 1.0f) || patience > 4.0f) return fail(ctx, MW_ERR_ARG, "mw_decode_beam: patience must be in [1, 4]");
+    if (n_audio < 1 || n_audio * beam > ctx->max_batch)
+        return fail(ctx, MW_ERR_ARG, "mw_decode_beam: n_audio * beam must be in 1.." + std::to_string(ctx->max_batch) + " (max_batch)");
+    if (ctx->enc_batch != n_audio) return fail(ctx, MW_ERR_STATE, "mw_decode_beam: n_audio differs from the last mw_encode");
+    if (!out_ids || !out_len) return fail(ctx, MW_ERR_ARG, "mw_decode_beam: null output");
+    HIPCHK(hipSetDevice(ctx->device));
+    const mw_model_desc& d = ctx->d;
+    const int R = n_audio * beam, P = (int)ctx->prompt.size(), max_new = ctx->max_new;
+    const int max_cand = (int)lroundf(beam * patience);
+    const int cand_cap = (int)lroundf(kMaxBeam * 4.0f);
+    if (!ctx->bm_sum_lp) {          // first use: sized for max_batch sequences and the largest candidate list
+        const size_t MB = ctx->max_batch;
+        ALLOC(ctx->bm_sum_lp, MB); ALLOC(ctx->bm_hist, MB * d.n_text_ctx); ALLOC(ctx->bm_src_rows, MB * d.n_text_ctx);
+        ALLOC(ctx->bm_fin_tokens, MB * cand_cap * d.n_text_ctx); ALLOC(ctx->bm_fin_lp, MB * cand_cap);
+        ALLOC(ctx->bm_fin_len, MB * cand_cap); ALLOC(ctx->bm_fin_count, MB); ALLOC(ctx->bm_completed, MB);
+    }
+    std::vector<int32_t> f((size_t)R * P);
+    for (int r = 0; r < R; ++r) memcpy(&f[(size_t)r * P], ctx->prompt.data(), P * 4);
+    HIPCHK(hipMemcpyAsync(ctx->forced, f.data(), f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+
+    BeamParams bp{};
+    bp.st = ctx->st; bp.n_audio = n_audio; bp.beam = beam; bp.max_cand = max_cand;
+    bp.logits = ctx->logits; bp.mask_first = ctx->mask_first; bp.mask_rest = ctx->mask_rest;
+    bp.forced = ctx->forced; bp.n_forced = P;
+    bp.tok_emb = ctx->tok_emb; bp.pos_emb = ctx->dec_pos; bp.D = d.d_model; bp.n_text_ctx = d.n_text_ctx; bp.vocab = d.vocab;
+    bp.x = ctx->dx; bp.sum_lp = ctx->bm_sum_lp; bp.hist = ctx->bm_hist; bp.src_rows = ctx->bm_src_rows;
+    bp.fin_tokens = ctx->bm_fin_tokens; bp.fin_lp = ctx->bm_fin_lp; bp.fin_len = ctx->bm_fin_len;
+    bp.fin_count = ctx->bm_fin_count; bp.completed = ctx->bm_completed;
+    hipStream_t s = ctx->stream;
+    launch_beam_init(bp, P, max_new, ctx->eot, s);
+    HIPCHK(hipGetLastError());
+    FinalizeParams fp = finalize_params(ctx, P);
+    const int n_steps = P + max_new - 1;
+    const bool graph = ctx->use_graph != 0;
+    if (graph) {
+        int r = ensure_graph(ctx, R, true, fp, (beam << 24) + (max_cand << 16) + R * 1024 + P, &bp);
+        if (r) return r;
+    }
+    int host_fin = 0, steps_run = 0;
+    for (int step = 0; step < n_steps; ++step) {
+        if (graph) HIPCHK(hipGraphLaunch(ctx->graph_exec, s));
+        else { enqueue_step(ctx, R, true, fp, &bp); HIPCHK(hipGetLastError()); }
+        ++steps_run;
+        if (step >= P - 1 && ((step - (P - 1)) % ctx->check_every) == ctx->check_every - 1 && step + 1 < n_steps) {
+            HIPCHK(hipMemcpyAsync(&host_fin, &ctx->st->n_finished, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (host_fin >= n_audio) break;
+        }
+    }
+    ctx->stage_ms[4] = (float)steps_run;
+    HIPCHK(hipEventRecord(ctx->ev[4], s));
+    // ---- collect: finished lists, live beams for the top-up, then rank by log-probability per token
+    std::vector<int32_t> hist((size_t)R * max_new), fin_tok((size_t)n_audio * max_cand * max_new), fin_len((size_t)n_audio * max_cand),
+        fin_count(n_audio);
+    std::vector<float> sum_lp(R), fin_lp((size_t)n_audio * max_cand);
+    HIPCHK(hipMemcpyAsync(hist.data(), ctx->bm_hist, hist.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(sum_lp.data(), ctx->bm_sum_lp, sum_lp.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(fin_tok.data(), ctx->bm_fin_tokens, fin_tok.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(fin_lp.data(), ctx->bm_fin_lp, fin_lp.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(fin_len.data(), ctx->bm_fin_len, fin_len.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(fin_count.data(), ctx->bm_fin_count, fin_count.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipEventElapsedTime(&ctx->stage_ms[3], ctx->ev[3], ctx->ev[4]));
+    // sampled tokens per live beam: every step run after the prompt appended one (the last token is chosen, not fed)
+    const int live_len = std::min(max_new, steps_run - (P - 1));
+    for (int a = 0; a < n_audio; ++a) {
+        struct Hyp { const int32_t* tok; int len; float lp; };
+        std::vector<Hyp> hyps;
+        for (int c = 0; c < fin_count[a]; ++c)
+            hyps.push_back({&fin_tok[((size_t)a * max_cand + c) * max_new], fin_len[(size_t)a * max_cand + c], fin_lp[(size_t)a * max_cand + c]});
+        if ((int)hyps.size() < beam) {               // top up with the best live beams (stable in beam order)
+            std::vector<int> order(beam);
+            for (int j = 0; j < beam; ++j) order[j] = j;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sum_lp[a * beam + x] > sum_lp[a * beam + y]; });
+            for (int j : order) {
+                if ((int)hyps.size() >= beam) break;
+                hyps.push_back({&hist[(size_t)(a * beam + j) * max_new], live_len, sum_lp[a * beam + j]});
+            }
+        }
+        int best = 0;
+        for (int i = 1; i < (int)hyps.size(); ++i)
+            if (hyps[i].lp / std::max(hyps[i].len, 1) > hyps[best].lp / std::max(hyps[best].len, 1)) best = i;
+        for (int i = 0; i < max_new; ++i) out_ids[(size_t)a * max_new + i] = i < hyps[best].len ? hyps[best].tok[i] : ctx->eot;
+        out_len[a] = hyps[best].len;
+        if (out_avg_logprob) out_avg_logprob[a] = hyps[best].lp / (hyps[best].len + 1);
+        for (int c = 0; c < beam; ++c) {
+            const bool have = c < (int)hyps.size();
+            if (hyp_len) hyp_len[a * beam + c] = have ? hyps[c].len : -1;
+            if (hyp_sum_logprob) hyp_sum_logprob[a * beam + c] = have ? hyps[c].lp : -INFINITY;
+            if (hyp_ids)
+                for (int i = 0; i < max_new; ++i)
+                    hyp_ids[((size_t)a * beam + c) * max_new + i] = (have && i < hyps[c].len) ? hyps[c].tok[i] : ctx->eot;
+        }
+    }
     return MW_OK;
 }
 

@@ -454,11 +454,17 @@ __global__ __launch_bounds__(512) void logits_kernel(GemvParams p) {
 // every partial back with agent-scope loads only after its own add has returned.
 constexpr int kPartStride = 68;     // floats per partial: max, sum, 64 outputs, 2 pad
 
-template <int NT, int RPT, int S>
+//
+// Beam search (several hypotheses per recording): `kv_div` > 1 makes sequence r read the cache of
+// recording r / kv_div (cross-attention: one encoder pass per recording, shared by its beams).  IND:
+// the self-attention cache is never reordered when beams change parents; instead `src_rows`
+// [position][sequence] names the physical cache row that holds each position of a sequence's history.
+template <int NT, int RPT, int S, bool IND = false>
 __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ kc,
                                                       const f16* __restrict__ vc, f16* __restrict__ out, int H,
                                                       int tstride, int nfixed, const DecState* __restrict__ st,
-                                                      float* __restrict__ partial, int* __restrict__ tickets) {
+                                                      float* __restrict__ partial, int* __restrict__ tickets,
+                                                      int kv_div, const int* __restrict__ src_rows, int n_rows) {
     constexpr int NG = NT / 8;            // row groups
     constexpr int NWV = NT / 64;
     __shared__ float part[NWV][64];
@@ -471,12 +477,31 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
     const int t0 = split * per;
     const int n = min(ntot, t0 + per) - t0;              // >= 1: S > 1 is only used with ntot >= S
     const int rg = tid >> 3, dc = tid & 7;
-    const f16* kb = kc + ((long)bh * tstride + t0) * 64 + dc * 8;
-    const f16* vb = vc + ((long)bh * tstride + t0) * 64 + dc * 8;
+    int seq = 0;
+    long bh_kv = bh;
+    if (IND || kv_div != 1) {           // greedy decoding never pays for these divisions
+        seq = bh / H;
+        bh_kv = (long)(seq / kv_div) * H + (bh - seq * H);
+    }
+    const f16* kb = kc + (bh_kv * tstride + t0) * 64 + dc * 8;
+    const f16* vb = vc + (bh_kv * tstride + t0) * 64 + dc * 8;
+    // element offset of row i of this thread from kb / vb (IND: through the cache-row table)
+    long roff[IND ? RPT : 1];
+    if constexpr (IND) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int t = min(rg + NG * i, n - 1);
+            roff[i] = ((long)(src_rows[(long)(t0 + t) * n_rows + seq] - seq) * H * tstride + t) * 64;
+        }
+    }
+    auto row_off = [&](int i) -> long {
+        if constexpr (IND) return roff[i];
+        else return (long)min(rg + NG * i, n - 1) * 64;
+    };
 
     half8 kv[RPT];
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) kv[i] = *reinterpret_cast<const half8*>(kb + (long)min(rg + NG * i, n - 1) * 64);
+    for (int i = 0; i < RPT; ++i) kv[i] = *reinterpret_cast<const half8*>(kb + row_off(i));
     float qv[8];
     {
         const half8 qh = *reinterpret_cast<const half8*>(q + (long)bh * 64 + dc * 8);
@@ -498,7 +523,7 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
         mx = fmaxf(mx, sv[i]);
     }
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) kv[i] = *reinterpret_cast<const half8*>(vb + (long)min(rg + NG * i, n - 1) * 64);
+    for (int i = 0; i < RPT; ++i) kv[i] = *reinterpret_cast<const half8*>(vb + row_off(i));
     // ---- softmax over all rows of the workgroup
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
@@ -639,6 +664,171 @@ __global__ __launch_bounds__(256) void dec_finalize_kernel(FinalizeParams p, int
     }
 }
 
+// ------------------------------------------------------------------ beam search bookkeeping
+// One workgroup per recording, once per step, in place of dec_finalize.  Restates, on the device,
+// the update of OpenAI Whisper's BeamSearchDecoder (decoding.py of the openai-whisper package; the
+// reference leaves decoding to whisperx's defaults, transcribe.py:111, and holds no such code):
+// every live beam proposes its beam+1 most likely tokens under the suppress mask; proposals are
+// ranked by cumulative log-probability (ties: beam order, then token rank); walking down, one that
+// ends in end-of-text joins the recording's finished list while that has room, any other becomes a
+// live beam until `beam` are chosen.  Beams that change parent take over the parent's token
+// history and its row of `src_rows`; the K/V cache itself never moves.
+// Before the first sampled token all beams of a recording are copies: only beam 0 carries weight
+// (the others start at -inf), which is what the reference algorithm's dictionary of sequences does.
+__global__ __launch_bounds__(256) void beam_init_kernel(BeamParams p, int prompt_len, int max_new, int eot) {
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const int R = p.n_audio * p.beam;
+    for (int j = 0; j < p.beam; ++j) {
+        const int r = a * p.beam + j;
+        const int tok = p.forced[(long)r * p.n_forced];
+        for (int c = tid; c < p.D; c += 256) p.x[(long)r * p.D + c] = (float)p.tok_emb[(long)tok * p.D + c] + (float)p.pos_emb[c];
+        for (int t = tid; t < p.n_text_ctx; t += 256) p.src_rows[(long)t * R + r] = r;
+        for (int i = tid; i < max_new; i += 256) p.hist[(long)r * max_new + i] = eot;
+        if (tid == 0) p.sum_lp[r] = j == 0 ? 0.f : -INFINITY;
+    }
+    if (tid == 0) { p.fin_count[a] = 0; p.completed[a] = 0; }
+    if (a == 0 && tid == 0) {
+        p.st->pos = 0; p.st->prompt_len = prompt_len; p.st->max_new = max_new; p.st->eot = eot;
+        p.st->n_finished = 0; p.st->batch = R;
+    }
+}
+
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
+    constexpr int KMAX = kMaxBeam + 1, NC = kMaxBeam * KMAX;
+    __shared__ float topv[KMAX][256];           // per-thread best-K lists (column = thread)
+    __shared__ int topi[KMAX][256];
+    __shared__ float wv[4]; __shared__ int wi[4]; __shared__ int wt[4];
+    __shared__ float redm[4], reds[4];
+    __shared__ float cand_lp[NC]; __shared__ int cand_tok[NC]; __shared__ int cand_rank[NC];
+    __shared__ int new_parent[kMaxBeam], new_tok[kMaxBeam]; __shared__ float new_lp[kMaxBeam];
+    __shared__ int fin_parent[NC]; __shared__ float fin_score[NC]; __shared__ int n_fin_new;
+    extern __shared__ int stage[];              // [beam][max(max_new, n_text_ctx)] history / cache-row staging
+
+    const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int beam = p.beam, K = beam + 1, R = p.n_audio * beam;
+    const int next = p.st->pos, prompt_len = p.st->prompt_len, max_new = p.st->max_new, eot = p.st->eot;
+    const int r0 = a * beam;
+    if (next < prompt_len || p.completed[a]) {      // forced prompt, or this recording has all its hypotheses
+        if (next < p.n_text_ctx)
+            for (int j = 0; j < beam; ++j) {
+                const int tok = next < prompt_len ? p.forced[(long)(r0 + j) * p.n_forced + next] : eot;
+                for (int c = tid; c < p.D; c += 256)
+                    p.x[(long)(r0 + j) * p.D + c] = (float)p.tok_emb[(long)tok * p.D + c] + (float)p.pos_emb[(long)next * p.D + c];
+            }
+        return;
+    }
+    const int sample = next - prompt_len;
+    const uint8_t* mask = sample == 0 ? p.mask_first : p.mask_rest;
+
+    // ---- per beam: log-sum-exp over the unmasked vocabulary and the K best tokens
+    for (int j = 0; j < beam; ++j) {
+        const float* lg = p.logits + (long)(r0 + j) * p.vocab;
+        for (int c = 0; c < K; ++c) { topv[c][tid] = -INFINITY; topi[c][tid] = 0x7fffffff; }
+        float m = -INFINITY, ssum = 0.f;
+        for (int i = tid; i < p.vocab; i += 256) {
+            if (mask[i]) continue;
+            const float v = lg[i];
+            if (v > m) { ssum = ssum * __expf(m - v) + 1.f; m = v; } else { ssum += __expf(v - m); }
+            if (v > topv[K - 1][tid]) {             // indices arrive in increasing order: ties keep the earlier one
+                int c = K - 1;
+                while (c > 0 && v > topv[c - 1][tid]) { topv[c][tid] = topv[c - 1][tid]; topi[c][tid] = topi[c - 1][tid]; --c; }
+                topv[c][tid] = v; topi[c][tid] = i;
+            }
+        }
+        // block log-sum-exp
+        float bm = wave_max(m);
+        if (lane == 0) redm[wave] = bm;
+        __syncthreads();
+        bm = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        float bs = wave_sum(m == -INFINITY ? 0.f : ssum * __expf(m - bm));
+        if (lane == 0) reds[wave] = bs;
+        __syncthreads();
+        const float lse = bm + __logf(reds[0] + reds[1] + reds[2] + reds[3]);
+        // K rounds: every thread offers the head of its list; the best (value, then lowest id) is popped
+        int head = 0;
+        for (int c = 0; c < K; ++c) {
+            float v = topv[head < K ? head : K - 1][tid];
+            int ix = topi[head < K ? head : K - 1][tid];
+            if (head >= K) { v = -INFINITY; ix = 0x7fffffff; }
+            int who = tid;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(v, o); const int oi = __shfl_xor(ix, o); const int ow = __shfl_xor(who, o);
+                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; who = ow; }
+            }
+            if (lane == 0) { wv[wave] = v; wi[wave] = ix; wt[wave] = who; }
+            __syncthreads();
+            float gv = wv[0]; int gi = wi[0], gt = wt[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+                if (wv[w] > gv || (wv[w] == gv && wi[w] < gi)) { gv = wv[w]; gi = wi[w]; gt = wt[w]; }
+            if (tid == gt) ++head;
+            if (tid == 0) {
+                cand_lp[j * K + c] = p.sum_lp[r0 + j] + (gv - lse);
+                cand_tok[j * K + c] = (gi >= 0 && gi < p.vocab) ? gi : eot;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- rank the beam*K proposals (descending score; ties keep proposal order)
+    const int nc = beam * K;
+    if (tid < nc) {
+        const float v = cand_lp[tid];
+        int rk = 0;
+        for (int k = 0; k < nc; ++k) rk += (cand_lp[k] > v || (cand_lp[k] == v && k < tid)) ? 1 : 0;
+        cand_rank[rk] = tid;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int saved = 0, nf = 0, room = p.max_cand - p.fin_count[a];
+        for (int k = 0; k < nc && saved < beam; ++k) {
+            const int c = cand_rank[k];
+            if (cand_tok[c] == eot) {
+                if (nf < room) { fin_parent[nf] = c / K; fin_score[nf] = cand_lp[c]; ++nf; }
+            } else {
+                new_parent[saved] = c / K; new_tok[saved] = cand_tok[c]; new_lp[saved] = cand_lp[c]; ++saved;
+            }
+        }
+        n_fin_new = nf;
+    }
+    __syncthreads();
+    // ---- finished hypotheses: the parent's history as it stands (end-of-text itself is not stored)
+    const int nf = n_fin_new, base = p.fin_count[a];
+    for (int f = 0; f < nf; ++f) {
+        const int* src = p.hist + (long)(r0 + fin_parent[f]) * max_new;
+        int* dst = p.fin_tokens + ((long)a * p.max_cand + base + f) * max_new;
+        for (int i = tid; i < sample; i += 256) dst[i] = src[i];
+        if (tid == 0) { p.fin_lp[a * p.max_cand + base + f] = fin_score[f]; p.fin_len[a * p.max_cand + base + f] = sample; }
+    }
+    // ---- live beams take over their parents' histories and cache rows (staged: parents may repeat)
+    const int width = max(max_new, p.n_text_ctx);
+    for (int j = 0; j < beam; ++j)
+        for (int i = tid; i < sample; i += 256) stage[j * width + i] = p.hist[(long)(r0 + j) * max_new + i];
+    __syncthreads();
+    for (int j = 0; j < beam; ++j) {
+        int* dst = p.hist + (long)(r0 + j) * max_new;
+        for (int i = tid; i < sample; i += 256) dst[i] = stage[new_parent[j] * width + i];
+        if (tid == 0 && sample < max_new) dst[sample] = new_tok[j];
+    }
+    __syncthreads();
+    for (int j = 0; j < beam; ++j)
+        for (int t = tid; t < next; t += 256) stage[j * width + t] = p.src_rows[(long)t * R + r0 + j];
+    __syncthreads();
+    for (int j = 0; j < beam; ++j)
+        for (int t = tid; t < next; t += 256) p.src_rows[(long)t * R + r0 + j] = stage[new_parent[j] * width + t];
+    if (tid < beam) p.sum_lp[r0 + tid] = new_lp[tid];
+    if (tid == 0) {
+        p.fin_count[a] = base + nf;
+        if (base + nf >= p.max_cand) { p.completed[a] = 1; atomicAdd(&p.st->n_finished, 1); }
+    }
+    if (next < p.n_text_ctx)
+        for (int j = 0; j < beam; ++j) {
+            const int tok = new_tok[j];
+            for (int c = tid; c < p.D; c += 256)
+                p.x[(long)(r0 + j) * p.D + c] = (float)p.tok_emb[(long)tok * p.D + c] + (float)p.pos_emb[(long)next * p.D + c];
+        }
+}
+
 template <int MT, int KPW, int XV, int R>
 void launch_gemv_r(const GemvParams& p, int nw, hipStream_t s) {
     size_t lds = (size_t)nw * R * MT * 64 * 16;
@@ -761,17 +951,21 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
 }
 
 void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx,
-                          const DecState* st, hipStream_t s) {
+                          const DecState* st, hipStream_t s, const int* src_rows) {
     // 512 threads = 64 row groups x 7 rows = 448 positions
-    hipLaunchKernelGGL((dec_attn_kernel<512, 7, 1>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st,
-                       (float*)nullptr, (int*)nullptr);
+    if (src_rows)
+        hipLaunchKernelGGL((dec_attn_kernel<512, 7, 1, true>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st,
+                           (float*)nullptr, (int*)nullptr, 1, src_rows, B);
+    else
+        hipLaunchKernelGGL((dec_attn_kernel<512, 7, 1>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st,
+                           (float*)nullptr, (int*)nullptr, 1, (const int*)nullptr, B);
 }
 
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
-                           int* tickets, hipStream_t s) {
+                           int* tickets, hipStream_t s, int kv_div) {
     // 4 key ranges of 375 frames per (sequence, head); 256 threads = 32 row groups x 12 rows = 384 >= 375
     hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, kc, vc, out, H,
-                       T, T, (const DecState*)nullptr, partial, tickets);
+                       T, T, (const DecState*)nullptr, partial, tickets, kv_div, (const int*)nullptr, B);
 }
 
 void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s) {
@@ -780,6 +974,15 @@ void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new
 
 void launch_dec_finalize(const FinalizeParams& p, int B, hipStream_t s) {
     hipLaunchKernelGGL(dec_finalize_kernel, dim3(B), dim3(256), 0, s, p, B);
+}
+
+void launch_beam_init(const BeamParams& p, int prompt_len, int max_new, int eot, hipStream_t s) {
+    hipLaunchKernelGGL(beam_init_kernel, dim3(p.n_audio), dim3(256), 0, s, p, prompt_len, max_new, eot);
+}
+
+void launch_beam_step(const BeamParams& p, hipStream_t s) {
+    const size_t lds = (size_t)p.beam * p.n_text_ctx * sizeof(int);      // n_text_ctx >= max_new
+    hipLaunchKernelGGL(beam_step_kernel, dim3(p.n_audio), dim3(256), lds, s, p);
 }
 
 }  // namespace mw

@@ -108,14 +108,16 @@ int gemv_logits_parts(int N);
 // raise the dynamic-LDS limit of every decode kernel instantiation once (not legal inside stream capture)
 void dec_kernels_prepare();
 
+// src_rows (beam search only, else null): int [Tctx][B], physical cache row of each cached position of each sequence
 void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx,
-                          const DecState* st, hipStream_t s);
+                          const DecState* st, hipStream_t s, const int* src_rows = nullptr);
 // Cross-attention splits each (sequence, head) over kXattnSplit workgroups; `partial` holds
 // B*H*kXattnSplit*68 floats and `tickets` B*H ints that must be zero before the first launch
 // (every launch leaves them zero again).
 constexpr int kXattnSplit = 4;
+// kv_div > 1: sequence r attends over the encoder cache of recording r / kv_div (the beams of one recording)
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
-                           int* tickets, hipStream_t s);
+                           int* tickets, hipStream_t s, int kv_div = 1);
 
 struct FinalizeParams {
     DecState* st;
@@ -129,6 +131,26 @@ struct FinalizeParams {
     int* finished;              // [B]
 };
 void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s);
+
+// ---------------------------------------------------------------- beam search bookkeeping
+constexpr int kMaxBeam = 8;
+struct BeamParams {
+    DecState* st;
+    int n_audio, beam, max_cand;            // sequences = n_audio * beam; max_cand finished hypotheses per recording
+    const float* logits;                    // [n_audio*beam][vocab] of this step
+    const uint8_t* mask_first; const uint8_t* mask_rest;
+    const int* forced; int n_forced;        // [n_audio*beam][n_forced]
+    const f16* tok_emb; const f16* pos_emb; int D; int n_text_ctx; int vocab;
+    float* x;                               // [n_audio*beam][D] next input embeddings
+    float* sum_lp;                          // [n_audio*beam] cumulative log-probability of each live beam
+    int* hist;                              // [n_audio*beam][max_new] sampled tokens of each live beam
+    int* src_rows;                          // [n_text_ctx][n_audio*beam] physical self-attention cache rows
+    int* fin_tokens;                        // [n_audio][max_cand][max_new]
+    float* fin_lp; int* fin_len;            // [n_audio][max_cand]
+    int* fin_count; int* completed;         // [n_audio]
+};
+void launch_beam_init(const BeamParams& p, int prompt_len, int max_new, int eot, hipStream_t s);
+void launch_beam_step(const BeamParams& p, hipStream_t s);
 void launch_dec_finalize(const FinalizeParams& p, int B, hipStream_t s);
 
 }  // namespace mw

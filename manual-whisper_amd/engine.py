@@ -166,6 +166,30 @@ class Engine:
                                                _ptr(logits) if want_logits else None), "mw_decode_greedy")
         return ids, lens, logits
 
+    def decode_beam(self, n_audio: int, beam: int = 5, patience: float = 1.0, want_hypotheses: bool = False):
+        """Beam search over the last ``encode(n_audio)``: -> (ids [n_audio, max_new], lens, avg_logprob)
+        and, with ``want_hypotheses``, (hyp_ids [n_audio, beam, max_new], hyp_len, hyp_sum_logprob)."""
+        if self.opts is None:
+            raise EngineError("set_decode_options first")
+        ids = np.empty((n_audio, self.opts.max_new), np.int32)
+        lens = np.empty(n_audio, np.int32)
+        avg = np.empty(n_audio, np.float32)
+        hi = np.empty((n_audio, beam, self.opts.max_new), np.int32) if want_hypotheses else None
+        hl = np.empty((n_audio, beam), np.int32) if want_hypotheses else None
+        hs = np.empty((n_audio, beam), np.float32) if want_hypotheses else None
+        self._check(self._lib.mw_decode_beam(self._h, n_audio, beam, C.c_float(patience), _ptr(ids), _ptr(lens), _ptr(avg),
+                                             _ptr(hi) if want_hypotheses else None, _ptr(hl) if want_hypotheses else None,
+                                             _ptr(hs) if want_hypotheses else None), "mw_decode_beam")
+        return (ids, lens, avg, hi, hl, hs) if want_hypotheses else (ids, lens, avg)
+
+    def transcribe_batch_beam(self, pcm, beam: int, patience: float = 1.0):
+        """log-mel -> encoder -> beam search for up to max_batch // beam chunks: -> (ids, lens), as transcribe_batch."""
+        n = self._pcm_batch(pcm)
+        self.logmel(pcm, want_output=False)
+        self.encode(n, want_output=False)
+        ids, lens, _ = self.decode_beam(n, beam, patience)
+        return ids, lens
+
     def decode_forced(self, tokens: np.ndarray) -> np.ndarray:
         tokens = np.ascontiguousarray(tokens, dtype=np.int32)
         B, n = tokens.shape

@@ -13,7 +13,9 @@ Differences that cannot be avoided offline, all stated where they bite:
     windows of at most 30 s by vad.py (energy detector + whisperx's hysteresis / merge rules; the
     neural VAD model does not exist offline); ``vad_options=None`` or ``{"vad_method": "fixed"}``
     gives fixed 30 s chunks.
-  * decoding is greedy without timestamps; text needs tokenizer.json, otherwise a segment's text is
+  * decoding is greedy by default (what the throughput figures are quoted on); ``asr_options={"beam_size": 5}``
+    switches to beam search at temperature 0 (whisperx's default beam; no temperature fallback), which runs
+    ``max_batch // beam_size`` chunks per pass.  No timestamps; text needs tokenizer.json, otherwise a segment's text is
     its token ids written as ``<|id|>`` and the ids are also returned under ``"tokens"``.
 """
 from __future__ import annotations
@@ -58,12 +60,15 @@ def _load_state_dict(path: str) -> dict:
 class Model:
     def __init__(self, engine: Engine, dims: WhisperDims, language: str, tokenizer=None,
                  initial_prompt: Optional[str] = None, vad_options: Optional[dict] = None,
-                 synthetic: bool = False, max_new: int = 224, n_engines: int = 1):
+                 synthetic: bool = False, max_new: int = 224, n_engines: int = 1, beam_size: int = 1, patience: float = 1.0):
         self.engine, self.dims, self.language = engine, dims, language
         self.tokenizer, self.initial_prompt = tokenizer, initial_prompt
         self.vad_options = dict(vad_options or {})
         self.synthetic, self.max_new = synthetic, max_new
-        self.pool = EnginePool(engine, n_engines)
+        if beam_size < 1 or beam_size > engine.max_batch:
+            raise EngineError(f"beam_size={beam_size} does not fit max_batch={engine.max_batch}")
+        self.beam_size, self.patience = int(beam_size), float(patience)
+        self.pool = EnginePool(engine, n_engines, self.beam_size, self.patience)
         self._opts_for = None
 
     # -- decoding rules ---------------------------------------------------------------
@@ -110,7 +115,7 @@ class Model:
         if self._opts_for != language:
             self.pool.set_decode_options(self.decode_options(language))
             self._opts_for = language
-        bs = max(1, min(int(batch_size), self.engine.max_batch))
+        bs = max(1, min(int(batch_size), self.engine.max_batch // self.beam_size))
         out = []
         for ids, lens in self.pool.map([chunks[a:b] for a, b in batches_of(len(chunks), bs)]):
             out.extend(ids[i, : lens[i]].copy() for i in range(ids.shape[0]))
@@ -173,4 +178,5 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
     engine.load_weights(weights)
     del weights
     return Model(engine, dims, language or "zh", tokenizer, asr_options.get("initial_prompt"), vad_options,
-                 synthetic=synthetic, max_new=int(asr_options.get("max_new_tokens", 224)), n_engines=n_engines)
+                 synthetic=synthetic, max_new=int(asr_options.get("max_new_tokens", 224)), n_engines=n_engines,
+                 beam_size=int(asr_options.get("beam_size", 1)), patience=float(asr_options.get("patience", 1.0)))

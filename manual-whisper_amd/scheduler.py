@@ -42,9 +42,10 @@ class EnginePool:
     the chip idle; a second and third engine (own stream and caches, shared weights) fill those gaps.
     """
 
-    def __init__(self, engine, n_engines: int = 1):
+    def __init__(self, engine, n_engines: int = 1, beam_size: int = 1, patience: float = 1.0):
         if n_engines < 1:
             raise ValueError("n_engines must be >= 1")
+        self.beam_size, self.patience = int(beam_size), float(patience)
         self.engines = [engine] + [engine.fork() for _ in range(n_engines - 1)]
         self._free: "queue.Queue" = queue.Queue()
         for e in self.engines:
@@ -58,6 +59,8 @@ class EnginePool:
     def _run(self, pcm):
         eng = self._free.get()
         try:
+            if self.beam_size > 1:
+                return eng.transcribe_batch_beam(pcm, self.beam_size, self.patience)
             return eng.transcribe_batch(pcm)
         finally:
             self._free.put(eng)

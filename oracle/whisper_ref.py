@@ -303,6 +303,104 @@ class WhisperOracle:
         lens[lens < 0] = max_new
         return ids, lens, (np.stack(all_logits) if return_logits else None)
 
+    # -- beam search ------------------------------------------------------------
+    def beam_search(self, enc, prompt, max_new, eot, beam_size=5, patience=1.0, suppress=(), begin_suppress=()):
+        """Beam search at temperature 0, as whisperx's default decoding does (the reference only
+        overrides ``initial_prompt``, transcribe.py:111).  The decoding code is not in the
+        reference tree; this restates the published algorithm of OpenAI Whisper's
+        ``BeamSearchDecoder`` / ``MaximumLikelihoodRanker`` (decoding.py of the openai-whisper
+        package, which faster-whisper mirrors): parity with the reference is unpinned.
+
+        Per audio, every live beam proposes its ``beam_size + 1`` most likely next tokens; the
+        proposals are ranked by cumulative log-probability; walking down the ranking, a proposal
+        that ends in ``eot`` joins the audio's finished list (until it holds
+        ``round(beam_size * patience)`` hypotheses), any other becomes a live beam until
+        ``beam_size`` are chosen.  Decoding stops when every audio's finished list is full or after
+        ``max_new`` tokens; lists that are not full are topped up with the best live beams.  The
+        winner maximises cumulative log-probability divided by its number of tokens.
+
+        Returns (ids int32 [B, max_new] padded with eot, lengths int32 [B], avg_logprob f32 [B],
+        all hypotheses per audio as a list of (tokens, sum_logprob)).
+        """
+        enc = np.asarray(enc, dtype=np.float32)
+        B = enc.shape[0]
+        n_beam = int(beam_size)
+        max_cand = int(round(n_beam * patience))
+        rep = np.repeat(np.arange(B), n_beam)
+        cross = [(k[rep], v[rep]) for k, v in self.cross_kv(enc)]
+        cache = [None] * self.d.dec_layers
+        sup = np.zeros(self.d.vocab, dtype=bool)
+        sup[list(suppress)] = True
+        bsup = sup.copy()
+        bsup[list(begin_suppress)] = True
+        R = B * n_beam
+        for pos, t in enumerate(prompt):
+            logits = self.decoder_step(np.full(R, t, dtype=np.int64), pos, cache, cross)
+        pos = len(prompt)
+        seqs = [[] for _ in range(R)]
+        sum_lp = np.zeros(R, np.float64)
+        finished = [dict() for _ in range(B)]
+        self.last_beam_margins = np.full(B, np.inf)      # per recording: smallest score gap at the edge of the beam
+        for n in range(max_new):
+            masked = np.where((bsup if n == 0 else sup)[None, :], -np.inf, logits.astype(np.float64))
+            mx = masked.max(axis=1, keepdims=True)
+            logp = masked - (mx + np.log(np.exp(masked - mx).sum(axis=1, keepdims=True)))
+            next_seqs, next_lp, parents = [], [], []
+            for b in range(B):
+                scores, sources = {}, {}
+                for j in range(n_beam):
+                    r = b * n_beam + j
+                    order = np.lexsort((np.arange(self.d.vocab), -logp[r]))[: n_beam + 1]     # ties: lowest id first
+                    for tok in order:
+                        key = tuple(seqs[r]) + (int(tok),)
+                        if key not in scores:                        # identical beams (first step) collapse
+                            scores[key] = sum_lp[r] + logp[r, tok]
+                            sources[key] = r
+                saved = 0
+                newly = {}
+                ranked = sorted(scores, key=lambda k_: -scores[k_])      # stable: insertion order breaks ties
+                for i_, key in enumerate(ranked):
+                    if key[-1] == eot:
+                        newly[key] = scores[key]
+                    else:
+                        next_seqs.append(list(key)); next_lp.append(scores[key]); parents.append(sources[key])
+                        saved += 1
+                        if saved == n_beam:
+                            if i_ + 1 < len(ranked) and len(finished[b]) < max_cand:    # how close the first proposal left out was
+                                self.last_beam_margins[b] = min(self.last_beam_margins[b], scores[key] - scores[ranked[i_ + 1]])
+                            break
+                for key in sorted(newly, key=lambda k_: -newly[k_]):
+                    if len(finished[b]) >= max_cand:
+                        break
+                    finished[b][key] = newly[key]
+            seqs, sum_lp = next_seqs, np.asarray(next_lp, np.float64)
+            parents = np.asarray(parents)
+            if all(len(f) >= max_cand for f in finished) or n == max_new - 1:
+                break
+            for i in range(self.d.dec_layers):
+                cache[i] = [cache[i][0][parents], cache[i][1][parents]]
+            logits = self.decoder_step(np.asarray([s_[-1] for s_ in seqs], np.int64), pos, cache, cross)
+            pos += 1
+        ids = np.full((B, max_new), eot, np.int32)
+        lens = np.zeros(B, np.int32)
+        avg = np.zeros(B, np.float32)
+        hyps = []
+        for b in range(B):
+            f = dict(finished[b])
+            if len(f) < n_beam:                                       # top up with the best live beams
+                for j in np.argsort(-sum_lp[b * n_beam:(b + 1) * n_beam], kind="stable"):
+                    f[tuple(seqs[b * n_beam + j]) + (eot,)] = sum_lp[b * n_beam + j]
+                    if len(f) >= n_beam:
+                        break
+            cand = [(list(k_[:-1]), float(v)) for k_, v in f.items()]
+            hyps.append(cand)
+            best = max(range(len(cand)), key=lambda i_: cand[i_][1] / max(len(cand[i_][0]), 1))
+            toks, lp = cand[best]
+            ids[b, : len(toks)] = toks
+            lens[b] = len(toks)
+            avg[b] = lp / (len(toks) + 1)
+        return ids, lens, avg, hyps
+
     def forced_logits(self, enc, tokens):
         """Teacher-forced logits: tokens int [B, n] -> f32 [B, n, vocab]."""
         enc = np.asarray(enc, dtype=np.float32)
