@@ -103,6 +103,34 @@ def test_config3_large_v3_batch16_properties(large):
     assert len({tuple(r) for r in a}) > 1, "all 16 chunks decoded to the same ids"
 
 
+def test_large_v3_beam_search_properties(large):
+    """Beam search at full size (3 recordings x 5 hypotheses = 15 sequences): a beam of one is greedy,
+    results repeat run to run and do not depend on which other recordings share the pass, every
+    hypothesis list is ranked and the winner maximises the per-token score."""
+    dims, eng, _ = large
+    opts = synthetic_options(dims, max_new=10, suppress_eot=True)
+    eng.set_decode_options(opts)
+    pcm = synth.make_pcm_np(3, seed=606)
+    eng.logmel(pcm, want_output=False)
+    eng.encode(3, want_output=False)
+    g_ids, g_lens = eng.decode_greedy(3)[:2]
+    b1 = eng.decode_beam(3, 1)
+    assert (b1[0] == g_ids).all() and (b1[1] == g_lens).all()
+    ids, lens, avg, hi, hl, hs = eng.decode_beam(3, 5, 1.0, want_hypotheses=True)
+    again = eng.decode_beam(3, 5, 1.0)
+    assert (again[0] == ids).all() and (again[2] == avg).all()
+    assert (hl == 10).all() and (lens == 10).all()                      # EOT suppressed: every hypothesis runs to max_new
+    for a in range(3):
+        assert len({tuple(hi[a, c]) for c in range(5)}) == 5           # five distinct hypotheses
+        best = int(np.argmax(hs[a] / hl[a]))
+        assert (ids[a] == hi[a, best]).all() and abs(avg[a] - hs[a, best] / 11) < 1e-5
+        assert hs[a].max() >= -1e-3 + np.float32(avg[a]) * 11
+    eng.logmel(pcm[1:2], want_output=False)
+    eng.encode(1, want_output=False)
+    one = eng.decode_beam(1, 5, 1.0)
+    assert (one[0][0] == ids[1]).all() and abs(one[2][0] - avg[1]) < 1e-6
+
+
 def test_config4_long_audio_chunk_bookkeeping():
     """One hour = 120 chunks: spans, batching and rank shards tile the recording exactly."""
     from manual_whisper_amd import parallel, scheduler
