@@ -86,7 +86,9 @@ struct mw_ctx {
     bool opts_set = false;
 
     // captured decode step
-    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; int graph_batch = 0; int graph_logits = -1;
+    // one captured step per self-attention context bucket (the launch geometry of that kernel follows the position)
+    hipGraph_t graph[kSelfAttnBuckets] = {}; hipGraphExec_t graph_exec[kSelfAttnBuckets] = {};
+    int graph_batch[kSelfAttnBuckets] = {}; int graph_logits[kSelfAttnBuckets] = {-1, -1, -1, -1};
 
     // timing
     hipEvent_t ev[6]{};
@@ -285,8 +287,10 @@ extern "C" void mw_destroy(mw_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
-    if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
+    for (int i = 0; i < kSelfAttnBuckets; ++i) {
+        if (ctx->graph_exec[i]) (void)hipGraphExecDestroy(ctx->graph_exec[i]);
+        if (ctx->graph[i]) (void)hipGraphDestroy(ctx->graph[i]);
+    }
     for (void* p : ctx->allocs) (void)hipFree(p);
     if (ctx->stage) (void)hipFree(ctx->stage);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -673,7 +677,7 @@ extern "C" int mw_encode(mw_ctx* ctx, const float* mel, int batch, float* enc_ou
 }
 
 // One greedy step: 8 launches per layer + final norm + logits + token bookkeeping.
-static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, const BeamParams* beam = nullptr) {
+static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int max_keys, const BeamParams* beam = nullptr) {
     const mw_model_desc& d = ctx->d;
     const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, Tc = d.n_text_ctx;
     hipStream_t s = ctx->stream;
@@ -697,7 +701,7 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
             p.out_mode = GV_QKV; p.out16 = ctx->dq; p.kcache = sk; p.vcache = sv;
             launch_gemv(p, s);
         }
-        launch_dec_self_attn(ctx->dq, sk, sv, ctx->datt, B, H, Tc, ctx->st, s, beam ? beam->src_rows : nullptr);
+        launch_dec_self_attn(ctx->dq, sk, sv, ctx->datt, B, H, Tc, ctx->st, s, beam ? beam->src_rows : nullptr, max_keys);
         {   GemvParams p = base(D, D, l.out); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
         {   // LN2 + cross-attention query
             GemvParams p = base(D, D, l.cq);
@@ -738,16 +742,21 @@ static FinalizeParams finalize_params(mw_ctx* ctx, int n_forced) {
     return fp;
 }
 
-// Capture (or re-use) the graph of one step for this batch size / forced length / logits flag.
-static int ensure_graph(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int key, const BeamParams* beam = nullptr) {
-    if (ctx->graph_exec && ctx->graph_batch == key && ctx->graph_logits == (int)want_logits) return MW_OK;
-    if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
-    if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
-    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    enqueue_step(ctx, B, want_logits, fp, beam);
-    HIPCHK(hipStreamEndCapture(ctx->stream, &ctx->graph));
-    HIPCHK(hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0));
-    ctx->graph_batch = key; ctx->graph_logits = (int)want_logits;
+// Capture (or re-use) the graph of one step for this batch size / forced length / logits flag and the
+// self-attention bucket of `n_keys` = position + 1.  Returns the executable graph through `out`.
+static int ensure_graph(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int key, int n_keys, hipGraphExec_t* out,
+                        const BeamParams* beam = nullptr) {
+    const int b = dec_self_attn_bucket(n_keys);
+    if (!(ctx->graph_exec[b] && ctx->graph_batch[b] == key && ctx->graph_logits[b] == (int)want_logits)) {
+        if (ctx->graph_exec[b]) { (void)hipGraphExecDestroy(ctx->graph_exec[b]); ctx->graph_exec[b] = nullptr; }
+        if (ctx->graph[b]) { (void)hipGraphDestroy(ctx->graph[b]); ctx->graph[b] = nullptr; }
+        HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        enqueue_step(ctx, B, want_logits, fp, n_keys, beam);
+        HIPCHK(hipStreamEndCapture(ctx->stream, &ctx->graph[b]));
+        HIPCHK(hipGraphInstantiate(&ctx->graph_exec[b], ctx->graph[b], nullptr, nullptr, 0));
+        ctx->graph_batch[b] = key; ctx->graph_logits[b] = (int)want_logits;
+    }
+    *out = ctx->graph_exec[b];
     return MW_OK;
 }
 
@@ -761,16 +770,16 @@ static int run_decode(mw_ctx* ctx, int B, int n_forced, int max_new, float* logi
     const bool want_logits = logits_out != nullptr;
     const int n_steps = max_new > 0 ? n_forced + max_new - 1 : n_forced;
     const bool graph = ctx->use_graph != 0;
-    if (graph) {
-        int r = ensure_graph(ctx, B, want_logits, fp, B * 1024 + n_forced);
-        if (r) return r;
-    }
     const size_t row = (size_t)B * d.vocab;
     int host_fin = 0;
     int steps_run = 0;
-    for (int step = 0; step < n_steps; ++step) {
-        if (graph) HIPCHK(hipGraphLaunch(ctx->graph_exec, s));
-        else { enqueue_step(ctx, B, want_logits, fp); HIPCHK(hipGetLastError()); }
+    for (int step = 0; step < n_steps; ++step) {       // step feeds position `step`: step + 1 cached keys
+        if (graph) {
+            hipGraphExec_t g;
+            int r = ensure_graph(ctx, B, want_logits, fp, B * 1024 + n_forced, step + 1, &g);
+            if (r) return r;
+            HIPCHK(hipGraphLaunch(g, s));
+        } else { enqueue_step(ctx, B, want_logits, fp, step + 1); HIPCHK(hipGetLastError()); }
         ++steps_run;
         if (want_logits) {
             // step feeds position `step`; its logits choose the token for position step + 1
@@ -859,14 +868,14 @@ extern "C" int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience
     FinalizeParams fp = finalize_params(ctx, P);
     const int n_steps = P + max_new - 1;
     const bool graph = ctx->use_graph != 0;
-    if (graph) {
-        int r = ensure_graph(ctx, R, true, fp, (beam << 24) + (max_cand << 16) + R * 1024 + P, &bp);
-        if (r) return r;
-    }
     int host_fin = 0, steps_run = 0;
     for (int step = 0; step < n_steps; ++step) {
-        if (graph) HIPCHK(hipGraphLaunch(ctx->graph_exec, s));
-        else { enqueue_step(ctx, R, true, fp, &bp); HIPCHK(hipGetLastError()); }
+        if (graph) {
+            hipGraphExec_t g;
+            int r = ensure_graph(ctx, R, true, fp, (beam << 24) + (max_cand << 16) + R * 1024 + P, step + 1, &g, &bp);
+            if (r) return r;
+            HIPCHK(hipGraphLaunch(g, s));
+        } else { enqueue_step(ctx, R, true, fp, step + 1, &bp); HIPCHK(hipGetLastError()); }
         ++steps_run;
         if (step >= P - 1 && ((step - (P - 1)) % ctx->check_every) == ctx->check_every - 1 && step + 1 < n_steps) {
             HIPCHK(hipMemcpyAsync(&host_fin, &ctx->st->n_finished, 4, hipMemcpyDeviceToHost, s));

@@ -950,15 +950,30 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
     if (mt == 1) (void)launch_gemv_mt<1>(p, s); else (void)launch_gemv_mt<2>(p, s);
 }
 
-void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx,
-                          const DecState* st, hipStream_t s, const int* src_rows) {
-    // 512 threads = 64 row groups x 7 rows = 448 positions
+template <int RPT>
+static void launch_self_attn_rpt(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx, const DecState* st,
+                                 hipStream_t s, const int* src_rows) {
     if (src_rows)
-        hipLaunchKernelGGL((dec_attn_kernel<512, 7, 1, true>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st,
+        hipLaunchKernelGGL((dec_attn_kernel<512, RPT, 1, true>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st,
                            (float*)nullptr, (int*)nullptr, 1, src_rows, B);
     else
-        hipLaunchKernelGGL((dec_attn_kernel<512, 7, 1>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st,
+        hipLaunchKernelGGL((dec_attn_kernel<512, RPT, 1>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st,
                            (float*)nullptr, (int*)nullptr, 1, (const int*)nullptr, B);
+}
+
+int dec_self_attn_bucket(int n_keys) { return n_keys <= 64 ? 0 : n_keys <= 128 ? 1 : n_keys <= 256 ? 2 : 3; }
+
+void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx,
+                          const DecState* st, hipStream_t s, const int* src_rows, int max_keys) {
+    // 512 threads = 64 row groups; a thread owns RPT cached positions.  The launch is sized for the
+    // keys that can exist (`max_keys` >= position + 1 of every step it will serve): rows past the
+    // context only cost duplicate loads, and at the start of a transcript that is most of them.
+    switch (dec_self_attn_bucket(max_keys)) {
+        case 0: launch_self_attn_rpt<1>(q, kc, vc, out, B, H, Tctx, st, s, src_rows); break;
+        case 1: launch_self_attn_rpt<2>(q, kc, vc, out, B, H, Tctx, st, s, src_rows); break;
+        case 2: launch_self_attn_rpt<4>(q, kc, vc, out, B, H, Tctx, st, s, src_rows); break;
+        default: launch_self_attn_rpt<7>(q, kc, vc, out, B, H, Tctx, st, s, src_rows); break;   // 448 positions
+    }
 }
 
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,

@@ -109,8 +109,12 @@ int gemv_logits_parts(int N);
 void dec_kernels_prepare();
 
 // src_rows (beam search only, else null): int [Tctx][B], physical cache row of each cached position of each sequence
+// max_keys: upper bound of position + 1 over the steps this launch (or its captured graph) serves; launches
+// with the same dec_self_attn_bucket(max_keys) are identical
 void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx,
-                          const DecState* st, hipStream_t s, const int* src_rows = nullptr);
+                          const DecState* st, hipStream_t s, const int* src_rows = nullptr, int max_keys = 1 << 30);
+int dec_self_attn_bucket(int n_keys);
+constexpr int kSelfAttnBuckets = 4;
 // Cross-attention splits each (sequence, head) over kXattnSplit workgroups; `partial` holds
 // B*H*kXattnSplit*68 floats and `tickets` B*H ints that must be zero before the first launch
 // (every launch leaves them zero again).
