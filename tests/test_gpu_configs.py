@@ -1,4 +1,4 @@
-"""Parity cases at the sizes BASELINE.json's configs name (beyond the micro/tiny fixtures).
+"""Parity cases at the sizes of the target configurations (beyond the micro/tiny fixtures).
 
 config 2: whisper-small fp16, batch 8          -> logits and ids against the oracle
 config 3: whisper-large-v3 fp16, batch 16      -> one chunk against the oracle at full size, and

@@ -29,7 +29,8 @@ __global__ void fill32(float* x, long n, unsigned seed, float scale, float offse
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 1280, K = argc > 2 ? atoi(argv[2]) : 1280, mode = argc > 3 ? atoi(argv[3]) : 0;
     const int B = argc > 4 ? atoi(argv[4]) : 16;
-    const int L = 32;
+    const int L = 32;                                     // launches per graph
+    const int NWT = getenv("HOT") ? 1 : L;               // HOT=1: every launch reads the same matrix (cache-resident weights)
     dec_kernels_prepare();
     f16 *W, *xin16, *out16, *lnscr; float *x32, *out32, *bias, *g, *b, *skp; int* skt; DecState* st;
     CK(hipMalloc(&W, (size_t)L * N * K * 2)); CK(hipMalloc(&xin16, (size_t)B * K * 2));
@@ -49,7 +50,7 @@ int main(int argc, char** argv) {
     auto enqueue = [&]() {
         for (int l = 0; l < L; ++l) {
             GemvParams p{};
-            p.B = B; p.N = N; p.K = K; p.W = W + (size_t)l * N * K; p.bias = bias; p.scale = 1.f; p.nv = 16; p.st = st;
+            p.B = B; p.N = N; p.K = K; p.W = W + (size_t)(l % NWT) * N * K; p.bias = bias; p.scale = 1.f; p.nv = 16; p.st = st;
             p.H = N / 64; p.D = N; p.Tctx = 448; p.ln_scratch = lnscr;
             p.sk_partial = skp; p.sk_partial_floats = splitk_partial_floats(N); p.sk_tickets = skt; p.sk_groups = splitk_groups(N);
             if (mode >= 2) { p.x32 = x32; p.ln_g = g; p.ln_b = b; p.gelu = mode == 3; p.out_mode = GV_F16; p.out16 = out16; }
