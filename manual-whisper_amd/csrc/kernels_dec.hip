@@ -459,7 +459,7 @@ constexpr int kPartStride = 68;     // floats per partial: max, sum, 64 outputs,
 // recording r / kv_div (cross-attention: one encoder pass per recording, shared by its beams).  IND:
 // the self-attention cache is never reordered when beams change parents; instead `src_rows`
 // [position][sequence] names the physical cache row that holds each position of a sequence's history.
-template <int NT, int RPT, int S, bool IND = false>
+template <int NT, int RPT, int S, bool IND = false, bool GRP = false>
 __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ kc,
                                                       const f16* __restrict__ vc, f16* __restrict__ out, int H,
                                                       int tstride, int nfixed, const DecState* __restrict__ st,
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
     const int rg = tid >> 3, dc = tid & 7;
     int seq = 0;
     long bh_kv = bh;
-    if (IND || kv_div != 1) {           // greedy decoding never pays for these divisions
+    if constexpr (IND || GRP) {         // compile-time: greedy decoding never reads kv_div (one more scalar-load round trip)
         seq = bh / H;
         bh_kv = (long)(seq / kv_div) * H + (bh - seq * H);
     }
@@ -979,8 +979,12 @@ void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, 
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
                            int* tickets, hipStream_t s, int kv_div) {
     // 4 key ranges of 375 frames per (sequence, head); 256 threads = 32 row groups x 12 rows = 384 >= 375
-    hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, kc, vc, out, H,
-                       T, T, (const DecState*)nullptr, partial, tickets, kv_div, (const int*)nullptr, B);
+    if (kv_div > 1)
+        hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, kc, vc,
+                           out, H, T, T, (const DecState*)nullptr, partial, tickets, kv_div, (const int*)nullptr, B);
+    else
+        hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, kc, vc, out, H,
+                           T, T, (const DecState*)nullptr, partial, tickets, 1, (const int*)nullptr, B);
 }
 
 void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s) {
