@@ -40,7 +40,7 @@ NEW_TOKENS = 128
 MODEL = "large-v3"
 
 
-def stage_rooflines(dims, batch, n_prompt, n_new, ms):
+def stage_rooflines(dims, batch, n_prompt, n_new, ms, layer_weight_bytes=2):
     """Algorithmic bytes / flops of each stage of one step over the stage's measured time (one
     engine alone on the GPU).  2*M*N*K per contraction, softmax/LayerNorm/GELU not counted."""
     D, F, T = dims.d_model, dims.ffn_dim, dims.n_audio_ctx
@@ -49,7 +49,7 @@ def stage_rooflines(dims, batch, n_prompt, n_new, ms):
                         + dims.enc_layers * (2 * T * (4 * D * D + 2 * D * F) + 4 * T * T * D))
     ckv_flop = batch * 2 * T * D * 2 * D * dims.dec_layers
     steps = n_prompt + n_new - 1
-    w_bytes = dims.dec_layers * (6 * D * D + 2 * D * F) * 2 + dims.vocab * D * 2
+    w_bytes = dims.dec_layers * (6 * D * D + 2 * D * F) * layer_weight_bytes + dims.vocab * D * 2
     ckv_bytes = batch * dims.dec_layers * 2 * T * D * 2
     self_bytes = sum(batch * dims.dec_layers * 2 * (t + 1) * D * 2 for t in range(steps))
     dec_bytes = steps * (w_bytes + ckv_bytes) + self_bytes
@@ -71,14 +71,14 @@ def stage_rooflines(dims, batch, n_prompt, n_new, ms):
     return out
 
 
-def cpu_baseline(dims, weights_np, opts, gpu_ids_fn):
+def cpu_baseline(dims, weights_np, opts, gpu_ids_fn, weight_format="f16"):
     """Oracle on the host: one 30 s chunk, 8 sampled tokens; decode time extrapolated to 128."""
     from threadpoolctl import threadpool_info
     from manual_whisper_amd import synth
     from oracle.whisper_ref import WhisperOracle, log_mel          # checker / baseline leg only
     sample_new = 8
     pcm = synth.make_pcm_np(1, seed=100)
-    orc = WhisperOracle(dims, weights_np)
+    orc = WhisperOracle(dims, weights_np, weight_format)
     t0 = time.perf_counter()
     mel = log_mel(pcm, dims.n_mels)
     t1 = time.perf_counter()
@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--engines", type=int, default=3, help="engines in flight per GPU (1 = strictly sequential steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weights", choices=("f16", "fp8"), default="f16",
+                    help="fp8: BASELINE configs[4] (e4m3 Linear weights, fp8 MFMA in the encoder); the default is the metric's configs[2]")
+    ap.add_argument("--batch", type=int, default=16, help="30 s chunks per step per GPU (configs[4] uses 32)")
     args = ap.parse_args()
 
     import torch
@@ -139,7 +142,8 @@ def main():
     dims = mw.get_dims(args.model)
     opts = synthetic_options(dims, max_new=NEW_TOKENS, suppress_eot=True)
     weights = synth.make_weights_torch(dims, seed=1234, device=dev)
-    eng = Engine(dims, device=local_rank, max_batch=BATCH)
+    batch = args.batch
+    eng = Engine(dims, device=local_rank, max_batch=batch, weight_format=args.weights)
     eng.load_weights(weights)
     eng.set_decode_options(opts)
     pool = EnginePool(eng, args.engines)
@@ -150,7 +154,7 @@ def main():
     torch.cuda.empty_cache()
 
     n_iter = args.warmup + args.steps
-    pcms = [synth.make_pcm_torch(BATCH, seed=1000 * rank + i, device=dev) for i in range(min(n_iter, 4))]
+    pcms = [synth.make_pcm_torch(batch, seed=1000 * rank + i, device=dev) for i in range(min(n_iter, 4))]
     for e in pool.engines:                      # set-up: every engine captures its decode graph once
         e.transcribe_batch(pcms[0])
 
@@ -184,29 +188,30 @@ def main():
     solo_ms = eng.stage_ms()
 
     # dominant kernel: decode-time cross-attention, HIP events on the engine's own stream
-    ca_ms, ca_bytes = eng.profile_cross_attention(BATCH, iters=256)
+    ca_ms, ca_bytes = eng.profile_cross_attention(batch, iters=256)
     achieved = ca_bytes / (ca_ms * 1e-3) / 1e9
 
     if rank == 0:
-        audio_s = world * BATCH * 30.0 * args.steps
+        audio_s = world * batch * 30.0 * args.steps
         out = {
             "metric": "audio-seconds transcribed/sec (RTF) large-v3 fp16, 30 s chunks, 1/2/4/8 GPU",
             "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/second",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
+            "dtype": "f16" if args.weights == "f16" else "fp8 weights (e4m3) / f16 activations, fp8 MFMA for the encoder's LayerNorm-fed products",
+            "data": "synthetic",
             "rtf": round(elapsed / audio_s, 6),
-            "config": {"workload": f"whisper-{args.model} fp16, batch={BATCH}x30 s chunks per GPU, greedy, "
+            "config": {"workload": f"whisper-{args.model} {'fp16' if args.weights == 'f16' else 'fp8 weights'}, batch={batch}x30 s chunks per GPU, greedy, "
                                    f"{len(opts.prompt)} prompt + {NEW_TOKENS} sampled tokens per chunk (EOT suppressed), "
                                    f"hipGraph decode step, {args.engines} engines (steps) in flight per GPU",
                        "parallelism": f"dp{world} over chunks, one all_gather of ids at the end"},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items() if k != "decode_steps"},
             "decode_steps_per_step": int(stage.get("decode_steps", 0)),
-            "stage_roofline": stage_rooflines(dims, BATCH, len(opts.prompt), NEW_TOKENS, solo_ms),
+            "stage_roofline": stage_rooflines(dims, batch, len(opts.prompt), NEW_TOKENS, solo_ms, 1 if args.weights == "fp8" else 2),
             "roofline": {"kernel": "dec_attn_kernel<256,12,4> (decode cross-attention, one launch per layer per token)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": XATTN_TRAFFIC_BYTES,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": XATTN_TRAFFIC_BYTES if batch == 16 else None,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/round1_hbm_counters.csv",
                          "bytes_per_launch": ca_bytes, "avg_launch_us": round(ca_ms * 1e3, 2)},
         }
@@ -216,7 +221,7 @@ def main():
                 eng.set_decode_options(o)
                 ids, _ = eng.transcribe_batch(pcm)
                 return ids
-            out["cpu_baseline"] = cpu_baseline(dims, weights_np, opts, gpu_ids)
+            out["cpu_baseline"] = cpu_baseline(dims, weights_np, opts, gpu_ids, args.weights)
         print(json.dumps(out), flush=True)
     pool.close()
     if world > 1:

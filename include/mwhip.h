@@ -41,6 +41,17 @@ typedef enum {
 
 typedef enum { MW_F32 = 0, MW_F16 = 1, MW_BF16 = 2 } mw_dtype;
 
+/* How the engine keeps the Linear weights of the encoder and decoder layers in HBM (what the
+ * compute_type argument of whisperx.load_model, reference transcribe.py:32,109, selects there).
+ *  MW_WEIGHTS_F16: fp16, fp32 accumulation everywhere.
+ *  MW_WEIGHTS_FP8: OCP e4m3 codes with one fp32 scale per output row (scale = max|w| / 448,
+ *    round to nearest even), quantised by mw_set_weight from whatever dtype arrives.  Encoder
+ *    products fed by a LayerNorm (QKV, MLP in) and the cross K/V projection run on the gfx950 fp8
+ *    MFMA with their input rows quantised the same way (one scale per row); every other product
+ *    multiplies fp16 activations with the exact fp16 image of the codes.  Convolutions,
+ *    embeddings, LayerNorm parameters and biases stay fp16/fp32. */
+typedef enum { MW_WEIGHTS_F16 = 0, MW_WEIGHTS_FP8 = 1 } mw_weight_format;
+
 /* Architecture of the checkpoint (what `MODEL_SIZE`, reference transcribe.py:33,
  * resolves to inside whisperx.load_model). head_dim must be 64. */
 typedef struct {
@@ -53,6 +64,7 @@ typedef struct {
     int32_t vocab;
     int32_t n_audio_ctx;   /* 1500 */
     int32_t n_text_ctx;    /* 448  */
+    int32_t weight_format; /* mw_weight_format; fp8 needs d_model and ffn_dim to be multiples of 128 */
 } mw_model_desc;
 
 /* Decoding rules; the asr_options / language arguments of whisperx.load_model

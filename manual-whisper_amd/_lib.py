@@ -21,7 +21,10 @@ SYMBOLS = (
 
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_mels", "d_model", "n_heads", "enc_layers", "dec_layers",
-                                          "ffn_dim", "vocab", "n_audio_ctx", "n_text_ctx")]
+                                          "ffn_dim", "vocab", "n_audio_ctx", "n_text_ctx", "weight_format")]
+
+
+WEIGHT_FORMATS = {"f16": 0, "fp8": 1}        # mw_weight_format
 
 
 class DecodeOpts(C.Structure):

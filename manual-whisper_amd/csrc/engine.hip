@@ -18,7 +18,8 @@ using namespace mw;
 
 static thread_local std::string g_create_error;
 
-struct LinearW { f16* w = nullptr; float* b = nullptr; };
+// fp16 weights in `w`; or, in an fp8 engine, OCP e4m3 codes in `w8` with one scale per output row in `ws`
+struct LinearW { f16* w = nullptr; float* b = nullptr; uint8_t* w8 = nullptr; float* ws = nullptr; };
 struct NormW { float* g = nullptr; float* b = nullptr; };
 
 struct EncLayerW { NormW ln1, ln2; LinearW qkv, out, fc1, fc2; };
@@ -44,6 +45,8 @@ struct mw_ctx {
     std::vector<DecLayerW> dec;
     NormW dec_ln;
     f16* ckv_w = nullptr; float* ckv_b = nullptr;         // [L][2D][D], [L][2D] (k part of the bias = 0)
+    uint8_t* ckv_w8 = nullptr; float* ckv_ws = nullptr;   // fp8 engine: [L][2D][D] codes, [L][2D] scales
+    bool fp8 = false;                                     // desc.weight_format == MW_WEIGHTS_FP8
     std::set<std::string> seen;
     bool enc_pos_set = false;
 
@@ -59,6 +62,8 @@ struct mw_ctx {
     float* logmel = nullptr; float* blockmax = nullptr;
     f16* melT = nullptr; f16* h1 = nullptr;
     float* x = nullptr; f16* xn = nullptr;
+    uint8_t* xn8 = nullptr; float* xs = nullptr;          // fp8 engine: quantised LayerNorm rows [M][D] + row scales [M]
+    f16* wexp = nullptr;                                  // fp8 engine: one weight matrix expanded to fp16 (max(D*D, D*F))
     f16 *q = nullptr, *k = nullptr, *vT = nullptr, *att = nullptr, *hid = nullptr, *enc_out = nullptr;
     float* enc_out32 = nullptr;
     f16 *crossK = nullptr, *crossV = nullptr;             // [L][B][H][1500][64]
@@ -182,6 +187,15 @@ static int build_mel_tables(mw_ctx* ctx) {
     return MW_OK;
 }
 
+static int alloc_linear(mw_ctx* ctx, LinearW& l, size_t out, size_t in, bool zero_bias = false) {
+    if (ctx->fp8) { ALLOC(l.w8, out * in); ALLOC(l.ws, out); }
+    else ALLOC(l.w, out * in);
+    ALLOC(l.b, out, zero_bias);
+    return MW_OK;
+}
+#define ALLOC_LINEAR(l, out, in, ...)                                   \
+    do { int r_ = alloc_linear(ctx, (l), (out), (in), ##__VA_ARGS__); if (r_) return r_; } while (0)
+
 static int alloc_weights(mw_ctx* ctx) {
     const mw_model_desc& d = ctx->d;
     const size_t D = d.d_model, F = d.ffn_dim, T = d.n_audio_ctx;
@@ -191,10 +205,10 @@ static int alloc_weights(mw_ctx* ctx) {
     ctx->enc.resize(d.enc_layers);
     for (auto& l : ctx->enc) {
         ALLOC(l.ln1.g, D); ALLOC(l.ln1.b, D); ALLOC(l.ln2.g, D); ALLOC(l.ln2.b, D);
-        ALLOC(l.qkv.w, 3 * D * D); ALLOC(l.qkv.b, 3 * D, true);
-        ALLOC(l.out.w, D * D); ALLOC(l.out.b, D);
-        ALLOC(l.fc1.w, F * D); ALLOC(l.fc1.b, F);
-        ALLOC(l.fc2.w, D * F); ALLOC(l.fc2.b, D);
+        ALLOC_LINEAR(l.qkv, 3 * D, D, true);
+        ALLOC_LINEAR(l.out, D, D);
+        ALLOC_LINEAR(l.fc1, F, D);
+        ALLOC_LINEAR(l.fc2, D, F);
     }
     ALLOC(ctx->enc_ln.g, D); ALLOC(ctx->enc_ln.b, D);
     ALLOC(ctx->tok_emb, (size_t)d.vocab * D);
@@ -202,15 +216,17 @@ static int alloc_weights(mw_ctx* ctx) {
     ctx->dec.resize(d.dec_layers);
     for (auto& l : ctx->dec) {
         ALLOC(l.ln1.g, D); ALLOC(l.ln1.b, D); ALLOC(l.ln2.g, D); ALLOC(l.ln2.b, D); ALLOC(l.ln3.g, D); ALLOC(l.ln3.b, D);
-        ALLOC(l.qkv.w, 3 * D * D); ALLOC(l.qkv.b, 3 * D, true);
-        ALLOC(l.out.w, D * D); ALLOC(l.out.b, D);
-        ALLOC(l.cq.w, D * D); ALLOC(l.cq.b, D);
-        ALLOC(l.co.w, D * D); ALLOC(l.co.b, D);
-        ALLOC(l.fc1.w, F * D); ALLOC(l.fc1.b, F);
-        ALLOC(l.fc2.w, D * F); ALLOC(l.fc2.b, D);
+        ALLOC_LINEAR(l.qkv, 3 * D, D, true);
+        ALLOC_LINEAR(l.out, D, D);
+        ALLOC_LINEAR(l.cq, D, D);
+        ALLOC_LINEAR(l.co, D, D);
+        ALLOC_LINEAR(l.fc1, F, D);
+        ALLOC_LINEAR(l.fc2, D, F);
     }
     ALLOC(ctx->dec_ln.g, D); ALLOC(ctx->dec_ln.b, D);
-    ALLOC(ctx->ckv_w, (size_t)d.dec_layers * 2 * D * D); ALLOC(ctx->ckv_b, (size_t)d.dec_layers * 2 * D, true);
+    if (ctx->fp8) { ALLOC(ctx->ckv_w8, (size_t)d.dec_layers * 2 * D * D); ALLOC(ctx->ckv_ws, (size_t)d.dec_layers * 2 * D); }
+    else ALLOC(ctx->ckv_w, (size_t)d.dec_layers * 2 * D * D);
+    ALLOC(ctx->ckv_b, (size_t)d.dec_layers * 2 * D, true);
     return MW_OK;
 }
 
@@ -227,6 +243,7 @@ static int alloc_work(mw_ctx* ctx) {
     ALLOC(ctx->melT, B * (size_t)(kFrames + 2) * d.n_mels, true);
     ALLOC(ctx->h1, B * (size_t)(kFrames + 2) * D, true);
     ALLOC(ctx->x, M * D); ALLOC(ctx->xn, M * D);
+    if (ctx->fp8) { ALLOC(ctx->xn8, M * D); ALLOC(ctx->xs, M); ALLOC(ctx->wexp, D * std::max(D, F)); }
     ALLOC(ctx->q, M * D); ALLOC(ctx->k, M * D);
     ALLOC(ctx->vT, B * H * 64 * (size_t)ctx->Tpad, true);
     ALLOC(ctx->att, M * D); ALLOC(ctx->hid, M * F);
@@ -260,6 +277,8 @@ extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, m
     if (d.n_audio_ctx != kFrames / 2 || d.n_text_ctx <= 0 || d.n_text_ctx > 448) { g_create_error = "mw_create: n_audio_ctx must be 1500 and n_text_ctx <= 448"; return MW_ERR_ARG; }
     if (max_batch < 1 || max_batch > 32) { g_create_error = "mw_create: max_batch must be in 1..32"; return MW_ERR_ARG; }
     if (d.vocab < 16 || d.enc_layers < 1 || d.dec_layers < 1) { g_create_error = "mw_create: bad vocab/layer count"; return MW_ERR_ARG; }
+    if (d.weight_format != MW_WEIGHTS_F16 && d.weight_format != MW_WEIGHTS_FP8) { g_create_error = "mw_create: weight_format must be MW_WEIGHTS_F16 or MW_WEIGHTS_FP8"; return MW_ERR_ARG; }
+    if (d.weight_format == MW_WEIGHTS_FP8 && (d.d_model % 128 || d.ffn_dim % 128)) { g_create_error = "mw_create: fp8 weights need d_model and ffn_dim to be multiples of 128"; return MW_ERR_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
         g_create_error = "mw_create: no such HIP device " + std::to_string(device) + " (" + std::to_string(ndev) + " visible)";
@@ -267,6 +286,7 @@ extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, m
     }
     mw_ctx* ctx = new mw_ctx();
     ctx->d = d; ctx->device = device; ctx->max_batch = max_batch;
+    ctx->fp8 = d.weight_format == MW_WEIGHTS_FP8;
     auto bail = [&](int code) { g_create_error = ctx->err; mw_destroy(ctx); return code; };
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(MW_ERR_HIP); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(MW_ERR_HIP); }
@@ -311,7 +331,8 @@ extern "C" int mw_fork(mw_ctx* parent, mw_ctx** out) {
     ctx->conv1_w = parent->conv1_w; ctx->conv1_b = parent->conv1_b; ctx->conv2_w = parent->conv2_w; ctx->conv2_b = parent->conv2_b;
     ctx->enc_pos = parent->enc_pos; ctx->enc = parent->enc; ctx->enc_ln = parent->enc_ln;
     ctx->tok_emb = parent->tok_emb; ctx->dec_pos = parent->dec_pos; ctx->dec = parent->dec; ctx->dec_ln = parent->dec_ln;
-    ctx->ckv_w = parent->ckv_w; ctx->ckv_b = parent->ckv_b;
+    ctx->ckv_w = parent->ckv_w; ctx->ckv_b = parent->ckv_b; ctx->ckv_w8 = parent->ckv_w8; ctx->ckv_ws = parent->ckv_ws;
+    ctx->fp8 = parent->fp8;
     ctx->basis_cos = parent->basis_cos; ctx->basis_sin = parent->basis_sin; ctx->filt = parent->filt; ctx->n_mels_pad = parent->n_mels_pad;
     ctx->prompt = parent->prompt; ctx->eot = parent->eot; ctx->max_new = parent->max_new; ctx->opts_set = parent->opts_set;
     auto bail = [&](int code) { parent->err = "mw_fork: " + ctx->err; mw_destroy(ctx); return code; };
@@ -348,12 +369,20 @@ extern "C" int mw_synchronize(mw_ctx* ctx) {
 // ---------------------------------------------------------------------------------------------
 // weights
 // ---------------------------------------------------------------------------------------------
-struct Slot { void* dst; long count; int to_f16; int conv_c; };   // conv_c > 0: permute [D][C][3] -> [D][3][C]
+// conv_c > 0: permute [D][C][3] -> [D][3][C].  dst8 != null: quantise [rows][cols] to e4m3 codes + row scales.
+struct Slot { void* dst; long count; int to_f16; int conv_c; uint8_t* dst8 = nullptr; float* sdst = nullptr; int rows = 0, cols = 0; };
 
 static bool resolve(mw_ctx* ctx, const std::string& name, Slot* s, std::vector<int64_t>* shape) {
     const mw_model_desc& d = ctx->d;
     const long D = d.d_model, F = d.ffn_dim;
     auto mat = [&](f16* p, long r, long c) { *s = {p, r * c, 1, 0}; *shape = {r, c}; return true; };
+    // a Linear weight (or `sec`-th [r][c] block of a stacked one): fp16, or e4m3 codes + scales in an fp8 engine
+    auto lin = [&](LinearW& l, long sec, long r, long c) {
+        if (!ctx->fp8) return mat(l.w + sec * r * c, r, c);
+        *s = {nullptr, r * c, 0, 0, l.w8 + sec * r * c, l.ws + sec * r, (int)r, (int)c};
+        *shape = {r, c};
+        return true;
+    };
     auto vec = [&](float* p, long n) { *s = {p, n, 0, 0}; *shape = {n}; return true; };
     auto norm = [&](NormW& n, const std::string& leaf) {
         if (leaf == "weight") return vec(n.g, D);
@@ -391,11 +420,11 @@ static bool resolve(mw_ctx* ctx, const std::string& name, Slot* s, std::vector<i
     auto proj = [&](LinearW& qkv, LinearW& out, const std::string& pj) {
         int sec = pj == "q_proj" ? 0 : pj == "k_proj" ? 1 : pj == "v_proj" ? 2 : pj == "out_proj" ? 3 : -1;
         if (sec < 0) return false;
-        if (sec == 3) return isw ? mat(out.w, D, D) : vec(out.b, D);
+        if (sec == 3) return isw ? lin(out, 0, D, D) : vec(out.b, D);
         if (sec == 1 && isb) return false;                             // k_proj has no bias (modeling_whisper.py:279)
-        return isw ? mat(qkv.w + sec * D * D, D, D) : vec(qkv.b + sec * D, D);
+        return isw ? lin(qkv, sec, D, D) : vec(qkv.b + sec * D, D);
     };
-    auto fc = [&](LinearW& l, long o, long i) { return isw ? mat(l.w, o, i) : vec(l.b, o); };
+    auto fc = [&](LinearW& l, long o, long i) { return isw ? lin(l, 0, o, i) : vec(l.b, o); };
 
     if (is_enc) {
         EncLayerW& l = ctx->enc[li];
@@ -410,10 +439,11 @@ static bool resolve(mw_ctx* ctx, const std::string& name, Slot* s, std::vector<i
     if (mod.rfind("self_attn.", 0) == 0) return proj(l.qkv, l.out, mod.substr(10));
     if (mod.rfind("encoder_attn.", 0) == 0) {
         const std::string pj = mod.substr(13);
-        if (pj == "q_proj") return isw ? mat(l.cq.w, D, D) : vec(l.cq.b, D);
-        if (pj == "out_proj") return isw ? mat(l.co.w, D, D) : vec(l.co.b, D);
-        if (pj == "k_proj") { if (isb) return false; return mat(ctx->ckv_w + (long)li * 2 * D * D, D, D); }
-        if (pj == "v_proj") return isw ? mat(ctx->ckv_w + (long)li * 2 * D * D + D * D, D, D) : vec(ctx->ckv_b + (long)li * 2 * D + D, D);
+        if (pj == "q_proj") return isw ? lin(l.cq, 0, D, D) : vec(l.cq.b, D);
+        if (pj == "out_proj") return isw ? lin(l.co, 0, D, D) : vec(l.co.b, D);
+        LinearW ckv{ctx->ckv_w, nullptr, ctx->ckv_w8, ctx->ckv_ws};            // all layers stacked: [L][2][D][D]
+        if (pj == "k_proj") { if (isb) return false; return lin(ckv, (long)li * 2, D, D); }
+        if (pj == "v_proj") return isw ? lin(ckv, (long)li * 2 + 1, D, D) : vec(ctx->ckv_b + (long)li * 2 * D + D, D);
         return false;
     }
     if (mod == "self_attn_layer_norm") return norm(l.ln1, leaf);
@@ -453,7 +483,8 @@ extern "C" int mw_set_weight(mw_ctx* ctx, const char* name_c, const void* data, 
         HIPCHK(hipMemcpy(ctx->stage, data, bytes, hipMemcpyHostToDevice));
         src = ctx->stage;
     }
-    if (s.conv_c > 0) launch_conv_permute(src, dtype, reinterpret_cast<f16*>(s.dst), (int)want[0], s.conv_c, ctx->stream);
+    if (s.dst8) launch_quant_rows(src, dtype, s.dst8, s.sdst, s.rows, s.cols, ctx->stream);
+    else if (s.conv_c > 0) launch_conv_permute(src, dtype, reinterpret_cast<f16*>(s.dst), (int)want[0], s.conv_c, ctx->stream);
     else launch_convert(src, dtype, s.dst, s.to_f16, s.count, ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));                      // the caller may free `data` on return
@@ -598,34 +629,45 @@ static int run_encoder(mw_ctx* ctx, int B) {
         p.gelu = 1; p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D;
         launch_gemm(p, s);
     }
+    // fp8 engine: the two products fed by a LayerNorm (QKV, MLP in) run on the fp8 MFMA, their input rows
+    // quantised by the LayerNorm launch itself; the two residual projections take fp16 activations as they
+    // come (attention output, GELU output) and the weight codes expanded to fp16, scales in the epilogue.
+    const bool f8 = ctx->fp8;
+    auto resid = [&](const f16* A, int K, const LinearW& w) {
+        GemmParams p = gemm_base(A, K, w.w, K, M, D, K, w.b);
+        if (f8) { launch_fp8_to_f16(w.w8, ctx->wexp, (long)D * K, s); p.W = ctx->wexp; p.w_scale = w.ws; }
+        p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D;
+        launch_gemm(p, s);
+    };
+    auto norm_in = [&](const NormW& n) -> const f16* {
+        if (f8) { launch_layernorm_fp8(ctx->x, n.g, n.b, ctx->xn8, ctx->xs, nullptr, M, D, s); return reinterpret_cast<const f16*>(ctx->xn8); }
+        launch_layernorm(ctx->x, n.g, n.b, ctx->xn, nullptr, M, D, s);
+        return ctx->xn;
+    };
+    auto fed_by_norm = [&](const f16* A, const LinearW& w, int N) {
+        GemmParams p = gemm_base(A, D, f8 ? reinterpret_cast<const f16*>(w.w8) : w.w, D, M, N, D, w.b);
+        if (f8) { p.f8 = 1; p.a_scale = ctx->xs; p.w_scale = w.ws; }
+        return p;
+    };
     for (int li = 0; li < d.enc_layers; ++li) {
         const EncLayerW& l = ctx->enc[li];
-        launch_layernorm(ctx->x, l.ln1.g, l.ln1.b, ctx->xn, nullptr, M, D, s);
         {
-            GemmParams p = gemm_base(ctx->xn, D, l.qkv.w, D, M, 3 * D, D, l.qkv.b);
+            GemmParams p = fed_by_norm(norm_in(l.ln1), l.qkv, 3 * D);
             p.scale = qscale; p.scale_ncols = D; p.out_mode = OUT_QKV_SPLIT;
             p.q = ctx->q; p.k = ctx->k; p.v = ctx->vT; p.T = T; p.Tpad = ctx->Tpad; p.H = H; p.D = D;
             launch_gemm(p, s);
         }
         launch_enc_attention(ctx->q, ctx->k, ctx->vT, ctx->att, B, H, T, ctx->Tpad, s);
+        resid(ctx->att, D, l.out);
         {
-            GemmParams p = gemm_base(ctx->att, D, l.out.w, D, M, D, D, l.out.b);
-            p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D;
-            launch_gemm(p, s);
-        }
-        launch_layernorm(ctx->x, l.ln2.g, l.ln2.b, ctx->xn, nullptr, M, D, s);
-        {
-            GemmParams p = gemm_base(ctx->xn, D, l.fc1.w, D, M, F, D, l.fc1.b);
+            GemmParams p = fed_by_norm(norm_in(l.ln2), l.fc1, F);
             p.gelu = 1; p.C = ctx->hid; p.ldc = F;
             launch_gemm(p, s);
         }
-        {
-            GemmParams p = gemm_base(ctx->hid, F, l.fc2.w, F, M, D, F, l.fc2.b);
-            p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D;
-            launch_gemm(p, s);
-        }
+        resid(ctx->hid, F, l.fc2);
     }
-    launch_layernorm(ctx->x, ctx->enc_ln.g, ctx->enc_ln.b, ctx->enc_out, ctx->enc_out32, M, D, s);
+    if (f8) launch_layernorm_fp8(ctx->x, ctx->enc_ln.g, ctx->enc_ln.b, ctx->xn8, ctx->xs, ctx->enc_out32, M, D, s);
+    else launch_layernorm(ctx->x, ctx->enc_ln.g, ctx->enc_ln.b, ctx->enc_out, ctx->enc_out32, M, D, s);
     HIPCHK(hipGetLastError());
     return MW_OK;
 }
@@ -636,6 +678,10 @@ static int run_cross_kv(mw_ctx* ctx, int B) {
     const size_t per_layer = (size_t)ctx->max_batch * T * D;
     for (int li = 0; li < d.dec_layers; ++li) {
         GemmParams p = gemm_base(ctx->enc_out, D, ctx->ckv_w + (size_t)li * 2 * D * D, D, M, 2 * D, D, ctx->ckv_b + (size_t)li * 2 * D);
+        if (ctx->fp8) {           // encoder output rows as the final LayerNorm quantised them (xn8, xs)
+            p.A = reinterpret_cast<const f16*>(ctx->xn8); p.W = reinterpret_cast<const f16*>(ctx->ckv_w8 + (size_t)li * 2 * D * D);
+            p.f8 = 1; p.a_scale = ctx->xs; p.w_scale = ctx->ckv_ws + (size_t)li * 2 * D;
+        }
         p.out_mode = OUT_KV_SPLIT; p.k = ctx->crossK + li * per_layer; p.v = ctx->crossV + li * per_layer;
         p.T = T; p.Tpad = T; p.H = H; p.D = D;
         launch_gemm(p, ctx->stream);
@@ -686,7 +732,7 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
     const size_t cross_layer = (size_t)ctx->max_batch * T * D;
     auto base = [&](int N, int K, const LinearW& w) {
         GemvParams p{};
-        p.B = B; p.N = N; p.K = K; p.W = w.w; p.bias = w.b; p.scale = 1.f; p.scale_ncols = 0; p.gelu = 0;
+        p.B = B; p.N = N; p.K = K; p.W = w.w; p.W8 = w.w8; p.w_scale = w.ws; p.bias = w.b; p.scale = 1.f; p.scale_ncols = 0; p.gelu = 0;
         p.H = H; p.D = D; p.Tctx = Tc; p.st = ctx->st; p.ln_scratch = ctx->dxn; p.nv = 16;
         p.sk_partial = ctx->skpartial; p.sk_partial_floats = splitk_partial_floats(D);
         p.sk_tickets = ctx->sktickets; p.sk_groups = splitk_groups(D);

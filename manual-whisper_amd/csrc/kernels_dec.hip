@@ -33,6 +33,22 @@ __device__ __forceinline__ float half_wave_sum(float v) {      // over the 32 la
     return v;
 }
 
+// 16 e4m3 codes (one 16-byte weight fragment) -> two fp16 MFMA operands: codes 0..7 and 8..15.
+// Every e4m3 value is exactly an fp16 value, so the product below is the product over the codes;
+// the per-row weight scale is applied to the accumulated sum in the epilogue.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void e4m3x16_to_f16(const uint4& w, half8& lo, half8& hi) {
+    const unsigned u[4] = {w.x, w.y, w.z, w.w};
+    half2v h[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        h[2 * d] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u[d], 1.0f, false);
+        h[2 * d + 1] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u[d], 1.0f, true);
+    }
+    lo = half8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+    hi = half8{h[4][0], h[4][1], h[5][0], h[5][1], h[6][0], h[6][1], h[7][0], h[7][1]};
+}
+
 // ------------------------------------------------------------------ skinny GEMM (weights streamed once)
 // out[b][n] = epi( sum_k X[b][k] * W[n][k] ),  b < B <= 16*MT.
 //
@@ -46,21 +62,29 @@ __device__ __forceinline__ float half_wave_sum(float v) {      // over the 32 la
 // fp32 residual rows are loaded once (32 lanes per row, XV float4 per lane), normalised in
 // registers (two-pass statistics, eps 1e-5) and staged in LDS as fp16 for all waves.
 // Partial sums of the waves are combined through LDS in a fixed order: bit-for-bit reproducible.
-template <int MT, int KPW, int XV, int R>
-__global__ void gemv_kernel(GemvParams p) {
+//
+// W8: the weights are e4m3 bytes with one fp32 scale per row.  A lane's 16-byte fragment then holds
+// 16 codes, so a k-step covers 64 columns (same bytes and the same access pattern per step as the
+// fp16 form, half as many steps): the fragment is expanded to two fp16 operands in registers and
+// meets the activation columns 16*fg .. 16*fg+7 and 16*fg+8 .. 16*fg+15 of the step.
+template <int MT, int KPW, int XV, int R, bool W8>
+__global__ __launch_bounds__(XV > 0 ? 512 : 1024) void gemv_kernel(GemvParams p) {      // the fused form always runs 512 threads
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NW = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int nv = p.nv;
     const int n0 = blockIdx.x * nv;
-    const f16* wp[R];
+    constexpr int KSTEP = W8 ? 64 : 32;          // columns per k-step (64 bytes of a weight row either way)
+    constexpr int XF = W8 ? 2 : 1;               // activation fragments per k-step
+    const char* wp[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int local = nv == 8 ? (fr & 7) : min(r * 16 + fr, nv - 1);
-        wp[r] = p.W + (long)min(n0 + local, p.N - 1) * p.K + fg * 8;
+        const long row = min(n0 + local, p.N - 1);
+        wp[r] = (W8 ? reinterpret_cast<const char*>(p.W8) + row * p.K : reinterpret_cast<const char*>(p.W) + row * p.K * 2) + fg * 16;
     }
-    const int nks = p.K >> 5;
+    const int nks = p.K / KSTEP;
 
     float4v* red = reinterpret_cast<float4v*>(smem);                       // [NW][R][MT][64]
     char* after_red = smem + (size_t)NW * R * MT * 64 * 16;
@@ -91,16 +115,17 @@ __global__ void gemv_kernel(GemvParams p) {
         const int ks = wave + NW * c;
         kval[c] = ks < nks;
 #pragma unroll
-        for (int r = 0; r < R; ++r) wreg[r][c] = *reinterpret_cast<const uint4*>(wp[r] + min(ks, nks - 1) * 32);
+        for (int r = 0; r < R; ++r) wreg[r][c] = *reinterpret_cast<const uint4*>(wp[r] + min(ks, nks - 1) * 64);
     }
     // epilogue operands: wave r finishes row tile r
     const int nl = wave * 16 + 4 * fg;
     const int n = n0 + nl;
     const bool owner = wave < R && nl < nv && n < p.N;                     // N and nv are multiples of 4
-    float4 bias4 = make_float4(0, 0, 0, 0);
+    float4 bias4 = make_float4(0, 0, 0, 0), ws4 = make_float4(1, 1, 1, 1);
     float4 res4[MT];
     if (owner) {
         if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+        if constexpr (W8) ws4 = *reinterpret_cast<const float4*>(p.w_scale + n);
         if (p.out_mode == GV_RESID) {
 #pragma unroll
             for (int t = 0; t < MT; ++t)
@@ -108,13 +133,16 @@ __global__ void gemv_kernel(GemvParams p) {
         }
     }
 
-    half8 xfrag[MT][KPW];
+    half8 xfrag[MT][KPW][XF];
     if constexpr (XV == 0) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            const f16* xr = p.xin16 + (long)min(t * 16 + fr, p.B - 1) * p.K + fg * 8;   // rows >= B: duplicates, never stored
+            const f16* xr = p.xin16 + (long)min(t * 16 + fr, p.B - 1) * p.K + fg * (8 * XF);   // rows >= B: duplicates, never stored
 #pragma unroll
-            for (int c = 0; c < KPW; ++c) xfrag[t][c] = *reinterpret_cast<const half8*>(xr + min(wave + NW * c, nks - 1) * 32);
+            for (int c = 0; c < KPW; ++c)
+#pragma unroll
+                for (int h = 0; h < XF; ++h)
+                    xfrag[t][c][h] = *reinterpret_cast<const half8*>(xr + min(wave + NW * c, nks - 1) * KSTEP + 8 * h);
         }
     } else {
         // LayerNorm of the fp32 rows, two-pass statistics in registers
@@ -155,7 +183,10 @@ __global__ void gemv_kernel(GemvParams p) {
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int c = 0; c < KPW; ++c)
-                xfrag[t][c] = *reinterpret_cast<const half8*>(xs + (t * 16 + fr) * ldx + min(wave + NW * c, nks - 1) * 32 + fg * 8);
+#pragma unroll
+                for (int h = 0; h < XF; ++h)
+                    xfrag[t][c][h] = *reinterpret_cast<const half8*>(xs + (t * 16 + fr) * ldx + min(wave + NW * c, nks - 1) * KSTEP +
+                                                                     fg * (8 * XF) + 8 * h);
     }
 
     float4v acc[R][MT];
@@ -167,14 +198,21 @@ __global__ void gemv_kernel(GemvParams p) {
     for (int c = 0; c < KPW; ++c) {
         // a k-step past the end is cancelled on the ACTIVATION side: a select on the weight register would
         // make everything scheduled before it wait for the weight stream
+        half8 wf[R][XF];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            half8 xf = xfrag[t][c];
-            if (!kval[c]) xf = half8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wreg[r][c]), xf, acc[r][t], 0, 0, 0);
+        for (int r = 0; r < R; ++r) {
+            if constexpr (W8) e4m3x16_to_f16(wreg[r][c], wf[r][0], wf[r][XF - 1]);
+            else wf[r][0] = *reinterpret_cast<half8*>(&wreg[r][c]);
         }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int h = 0; h < XF; ++h) {
+                half8 xf = xfrag[t][c][h];
+                if (!kval[c]) xf = half8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[r][h], xf, acc[r][t], 0, 0, 0);
+            }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -190,7 +228,13 @@ __global__ void gemv_kernel(GemvParams p) {
         const int m = t * 16 + fr;
         if (m >= p.B) continue;
         float4v v = {bias4.x, bias4.y, bias4.z, bias4.w};
-        for (int w = 0; w < NW; ++w) v += red[((w * R + wave) * MT + t) * 64 + lane];
+        if constexpr (W8) {
+            float4v a = red[(wave * MT + t) * 64 + lane];       // w = 0
+            for (int w = 1; w < NW; ++w) a += red[((w * R + wave) * MT + t) * 64 + lane];
+            v[0] += a[0] * ws4.x; v[1] += a[1] * ws4.y; v[2] += a[2] * ws4.z; v[3] += a[3] * ws4.w;
+        } else {
+            for (int w = 0; w < NW; ++w) v += red[((w * R + wave) * MT + t) * 64 + lane];
+        }
         if (n < p.scale_ncols) v *= p.scale;
         if (p.gelu) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
         if (p.out_mode == GV_RESID) {
@@ -227,40 +271,47 @@ __global__ void gemv_kernel(GemvParams p) {
 constexpr int kSplitKWaves = 4;
 constexpr int kSplitKMax = 8;
 
-template <int MT, int KPW, int R>
+template <int MT, int KPW, int R, bool W8>
 __global__ __launch_bounds__(kSplitKWaves * 64) void gemv_splitk_kernel(GemvParams p, int ks_per) {
     constexpr int NW = kSplitKWaves, NT = R * MT;       // NT accumulator tiles per wave
+    constexpr int KSTEP = W8 ? 64 : 32, XF = W8 ? 2 : 1;   // as in gemv_kernel
     __shared__ float4v red[NW][NT][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int S = gridDim.y, split = blockIdx.y, rg = blockIdx.x;
     const int n0 = rg * 16 * R;
-    const int nks = p.K >> 5;
+    const int nks = p.K / KSTEP;
     const int k0 = split * ks_per;
     const int kend = min(nks, k0 + ks_per);             // > k0: the launcher never creates an empty range
 
     uint4 wreg[R][KPW];
-    half8 xfrag[MT][KPW];
+    half8 xfrag[MT][KPW][XF];
     bool kval[KPW];
+    const char* wbase = W8 ? reinterpret_cast<const char*>(p.W8) : reinterpret_cast<const char*>(p.W);
+    const long wrow_bytes = W8 ? p.K : 2L * p.K;
 #pragma unroll
     for (int c = 0; c < KPW; ++c) {
         const int ks = k0 + wave + NW * c;
         kval[c] = ks < kend;
-        const int kc = min(ks, kend - 1) * 32 + fg * 8;
+        const int kstep = min(ks, kend - 1);
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            wreg[r][c] = *reinterpret_cast<const uint4*>(p.W + (long)(n0 + r * 16 + fr) * p.K + kc);
+            wreg[r][c] = *reinterpret_cast<const uint4*>(wbase + (long)(n0 + r * 16 + fr) * wrow_bytes + kstep * 64 + fg * 16);
 #pragma unroll
         for (int t = 0; t < MT; ++t)
-            xfrag[t][c] = *reinterpret_cast<const half8*>(p.xin16 + (long)min(t * 16 + fr, p.B - 1) * p.K + kc);
+#pragma unroll
+            for (int h = 0; h < XF; ++h)
+                xfrag[t][c][h] = *reinterpret_cast<const half8*>(p.xin16 + (long)min(t * 16 + fr, p.B - 1) * p.K + kstep * KSTEP +
+                                                                 fg * (8 * XF) + 8 * h);
     }
     // epilogue operands of the merging wave (only the last arriver uses them)
-    float4 bias4[R], res4[NT];
+    float4 bias4[R], ws4[R], res4[NT];
     if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int n = n0 + r * 16 + 4 * fg;
             bias4[r] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+            ws4[r] = W8 ? *reinterpret_cast<const float4*>(p.w_scale + n) : make_float4(1, 1, 1, 1);
 #pragma unroll
             for (int t = 0; t < MT; ++t)
                 res4[r * MT + t] = *reinterpret_cast<const float4*>(p.out32 + (long)min(t * 16 + fr, p.B - 1) * p.N + n);
@@ -272,14 +323,22 @@ __global__ __launch_bounds__(kSplitKWaves * 64) void gemv_splitk_kernel(GemvPara
     for (int i = 0; i < NT; ++i) acc[i] = float4v{0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < KPW; ++c) {
+        half8 wf[R][XF];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            half8 xf = xfrag[t][c];
-            if (!kval[c]) xf = half8{0, 0, 0, 0, 0, 0, 0, 0};           // cancel on the activation side (see gemv_kernel)
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                acc[r * MT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wreg[r][c]), xf, acc[r * MT + t], 0, 0, 0);
+        for (int r = 0; r < R; ++r) {
+            if constexpr (W8) e4m3x16_to_f16(wreg[r][c], wf[r][0], wf[r][XF - 1]);
+            else wf[r][0] = *reinterpret_cast<half8*>(&wreg[r][c]);
         }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int h = 0; h < XF; ++h) {
+                half8 xf = xfrag[t][c][h];
+                if (!kval[c]) xf = half8{0, 0, 0, 0, 0, 0, 0, 0};       // cancel on the activation side (see gemv_kernel)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    acc[r * MT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[r][h], xf, acc[r * MT + t], 0, 0, 0);
+            }
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) red[wave][i][lane] = acc[i];
@@ -331,8 +390,10 @@ __global__ __launch_bounds__(kSplitKWaves * 64) void gemv_splitk_kernel(GemvPara
             const int m = t * 16 + fr, i = r * MT + t;
             if (m >= p.B) continue;
             *reinterpret_cast<float4*>(p.out32 + (long)m * p.N + n) =
-                make_float4(res4[i].x + (acc[i][0] + bias4[r].x), res4[i].y + (acc[i][1] + bias4[r].y),
-                            res4[i].z + (acc[i][2] + bias4[r].z), res4[i].w + (acc[i][3] + bias4[r].w));
+                W8 ? make_float4(res4[i].x + (acc[i][0] * ws4[r].x + bias4[r].x), res4[i].y + (acc[i][1] * ws4[r].y + bias4[r].y),
+                                 res4[i].z + (acc[i][2] * ws4[r].z + bias4[r].z), res4[i].w + (acc[i][3] * ws4[r].w + bias4[r].w))
+                   : make_float4(res4[i].x + (acc[i][0] + bias4[r].x), res4[i].y + (acc[i][1] + bias4[r].y),
+                                 res4[i].z + (acc[i][2] + bias4[r].z), res4[i].w + (acc[i][3] + bias4[r].w));
         }
     }
 }
@@ -829,85 +890,122 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
         }
 }
 
-template <int MT, int KPW, int XV, int R>
+template <int MT, int KPW, int XV, int R, bool W8>
 void launch_gemv_r(const GemvParams& p, int nw, hipStream_t s) {
     size_t lds = (size_t)nw * R * MT * 64 * 16;
     if (XV > 0) lds += (size_t)2 * p.K * 4 + (size_t)16 * MT * (p.K + 8) * 2;
-    hipLaunchKernelGGL((gemv_kernel<MT, KPW, XV, R>), dim3((p.N + p.nv - 1) / p.nv), dim3(nw * 64), lds, s, p);
+    hipLaunchKernelGGL((gemv_kernel<MT, KPW, XV, R, W8>), dim3((p.N + p.nv - 1) / p.nv), dim3(nw * 64), lds, s, p);
 }
-template <int MT, int KPW, int XV>
+template <int MT, int KPW, int XV, bool W8>
 void launch_gemv_t(const GemvParams& p, int nw, hipStream_t s) {
     if constexpr (XV > 0) {                 // two row tiles exist for the fused kernels only (the MLP's first matrix)
-        if (p.nv > 16) { launch_gemv_r<MT, KPW, XV, 2>(p, nw, s); return; }
+        if (p.nv > 16) { launch_gemv_r<MT, KPW, XV, 2, W8>(p, nw, s); return; }
     }
-    launch_gemv_r<MT, KPW, XV, 1>(p, nw, s);
+    launch_gemv_r<MT, KPW, XV, 1, W8>(p, nw, s);
 }
 
 constexpr int kMaxLds = 160 * 1024;
 
-template <int MT, int KPW, int XV>
+template <int MT, int KPW, int XV, bool W8>
 void prepare_gemv_t() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<MT, KPW, XV, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<MT, KPW, XV, 1, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     if constexpr (XV > 0)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<MT, KPW, XV, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<MT, KPW, XV, 2, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
 }
 template <int MT>
 void prepare_mt() {
-    prepare_gemv_t<MT, 1, 1>(); prepare_gemv_t<MT, 2, 3>(); prepare_gemv_t<MT, 2, 4>(); prepare_gemv_t<MT, 3, 6>();
-    prepare_gemv_t<MT, 4, 8>(); prepare_gemv_t<MT, 5, 10>();
-    prepare_gemv_t<MT, 1, 0>(); prepare_gemv_t<MT, 2, 0>(); prepare_gemv_t<MT, 3, 0>(); prepare_gemv_t<MT, 4, 0>();
-    prepare_gemv_t<MT, 5, 0>(); prepare_gemv_t<MT, 6, 0>(); prepare_gemv_t<MT, 8, 0>(); prepare_gemv_t<MT, 10, 0>();
+    prepare_gemv_t<MT, 1, 1, false>(); prepare_gemv_t<MT, 2, 3, false>(); prepare_gemv_t<MT, 2, 4, false>(); prepare_gemv_t<MT, 3, 6, false>();
+    prepare_gemv_t<MT, 4, 8, false>(); prepare_gemv_t<MT, 5, 10, false>();
+    prepare_gemv_t<MT, 1, 0, false>(); prepare_gemv_t<MT, 2, 0, false>(); prepare_gemv_t<MT, 3, 0, false>(); prepare_gemv_t<MT, 4, 0, false>();
+    prepare_gemv_t<MT, 5, 0, false>(); prepare_gemv_t<MT, 6, 0, false>(); prepare_gemv_t<MT, 8, 0, false>(); prepare_gemv_t<MT, 10, 0, false>();
+    // e4m3 weights: k-steps of 64 columns, so half the steps per wave
+    prepare_gemv_t<MT, 1, 1, true>(); prepare_gemv_t<MT, 1, 3, true>(); prepare_gemv_t<MT, 1, 4, true>(); prepare_gemv_t<MT, 2, 6, true>();
+    prepare_gemv_t<MT, 2, 8, true>(); prepare_gemv_t<MT, 3, 10, true>();
+    prepare_gemv_t<MT, 1, 0, true>(); prepare_gemv_t<MT, 2, 0, true>(); prepare_gemv_t<MT, 3, 0, true>(); prepare_gemv_t<MT, 4, 0, true>();
+    prepare_gemv_t<MT, 5, 0, true>();
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(logits_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
 }
 
-template <int MT>
+template <int MT, bool W8>
 bool launch_gemv_mt(const GemvParams& p, hipStream_t s) {
-    const int nks = p.K / 32;
+    const int nks = p.K / (W8 ? 64 : 32);
     if (p.ln_g) {                   // fused LayerNorm: K = d_model, 512 threads
-        switch (p.K) {
-            case 128: launch_gemv_t<MT, 1, 1>(p, 8, s); return true;
-            case 384: launch_gemv_t<MT, 2, 3>(p, 8, s); return true;
-            case 512: launch_gemv_t<MT, 2, 4>(p, 8, s); return true;
-            case 768: launch_gemv_t<MT, 3, 6>(p, 8, s); return true;
-            case 1024: launch_gemv_t<MT, 4, 8>(p, 8, s); return true;
-            case 1280: launch_gemv_t<MT, 5, 10>(p, 8, s); return true;
-            default: break;
+        if constexpr (W8) {
+            switch (p.K) {
+                case 128: launch_gemv_t<MT, 1, 1, true>(p, 8, s); return true;
+                case 384: launch_gemv_t<MT, 1, 3, true>(p, 8, s); return true;
+                case 512: launch_gemv_t<MT, 1, 4, true>(p, 8, s); return true;
+                case 768: launch_gemv_t<MT, 2, 6, true>(p, 8, s); return true;
+                case 1024: launch_gemv_t<MT, 2, 8, true>(p, 8, s); return true;
+                case 1280: launch_gemv_t<MT, 3, 10, true>(p, 8, s); return true;
+                default: break;
+            }
+        } else {
+            switch (p.K) {
+                case 128: launch_gemv_t<MT, 1, 1, false>(p, 8, s); return true;
+                case 384: launch_gemv_t<MT, 2, 3, false>(p, 8, s); return true;
+                case 512: launch_gemv_t<MT, 2, 4, false>(p, 8, s); return true;
+                case 768: launch_gemv_t<MT, 3, 6, false>(p, 8, s); return true;
+                case 1024: launch_gemv_t<MT, 4, 8, false>(p, 8, s); return true;
+                case 1280: launch_gemv_t<MT, 5, 10, false>(p, 8, s); return true;
+                default: break;
+            }
         }
         // no fused instantiation for this width: separate LayerNorm launch, then the plain form
         launch_layernorm(p.x32, p.ln_g, p.ln_b, p.ln_scratch, nullptr, p.B, p.K, s);
         GemvParams q = p;
         q.ln_g = nullptr; q.ln_b = nullptr; q.xin16 = p.ln_scratch;
         if (q.nv > 16) q.nv = 16;               // the plain form has one row tile
-        return launch_gemv_mt<MT>(q, s);
+        return launch_gemv_mt<MT, W8>(q, s);
     }
     const int nw = nks >= 48 ? 16 : nks >= 16 ? 8 : 4;
     const int kpw = (nks + nw - 1) / nw;
-    switch (kpw) {
-        case 1: launch_gemv_t<MT, 1, 0>(p, nw, s); return true;
-        case 2: launch_gemv_t<MT, 2, 0>(p, nw, s); return true;
-        case 3: launch_gemv_t<MT, 3, 0>(p, nw, s); return true;
-        case 4: launch_gemv_t<MT, 4, 0>(p, nw, s); return true;
-        case 5: launch_gemv_t<MT, 5, 0>(p, nw, s); return true;
-        case 6: launch_gemv_t<MT, 6, 0>(p, nw, s); return true;
-        case 7: case 8: launch_gemv_t<MT, 8, 0>(p, nw, s); return true;
-        case 9: case 10: launch_gemv_t<MT, 10, 0>(p, nw, s); return true;
-        default: return false;      // K > 5120
+    if constexpr (W8) {
+        switch (kpw) {
+            case 1: launch_gemv_t<MT, 1, 0, true>(p, nw, s); return true;
+            case 2: launch_gemv_t<MT, 2, 0, true>(p, nw, s); return true;
+            case 3: launch_gemv_t<MT, 3, 0, true>(p, nw, s); return true;
+            case 4: launch_gemv_t<MT, 4, 0, true>(p, nw, s); return true;
+            case 5: launch_gemv_t<MT, 5, 0, true>(p, nw, s); return true;
+            default: return false;      // K > 5120
+        }
+    } else {
+        switch (kpw) {
+            case 1: launch_gemv_t<MT, 1, 0, false>(p, nw, s); return true;
+            case 2: launch_gemv_t<MT, 2, 0, false>(p, nw, s); return true;
+            case 3: launch_gemv_t<MT, 3, 0, false>(p, nw, s); return true;
+            case 4: launch_gemv_t<MT, 4, 0, false>(p, nw, s); return true;
+            case 5: launch_gemv_t<MT, 5, 0, false>(p, nw, s); return true;
+            case 6: launch_gemv_t<MT, 6, 0, false>(p, nw, s); return true;
+            case 7: case 8: launch_gemv_t<MT, 8, 0, false>(p, nw, s); return true;
+            case 9: case 10: launch_gemv_t<MT, 10, 0, false>(p, nw, s); return true;
+            default: return false;      // K > 5120
+        }
     }
 }
 
-template <int MT, int R>
+template <int MT, int R, bool W8>
 bool launch_splitk_r(const GemvParams& p, int S, hipStream_t s) {
-    const int nks = p.K / 32;
+    const int nks = p.K / (W8 ? 64 : 32);
     const int ks_per = (nks + S - 1) / S;
     S = (nks + ks_per - 1) / ks_per;                    // drop ranges that would be empty
     const int kpw = (ks_per + kSplitKWaves - 1) / kSplitKWaves;
     const dim3 grid(p.N / (16 * R), S), block(kSplitKWaves * 64);
     switch (kpw) {
-#define MW_SK_CASE(KPW) case KPW: hipLaunchKernelGGL((gemv_splitk_kernel<MT, KPW, R>), grid, block, 0, s, p, ks_per); return true;
-        MW_SK_CASE(1) MW_SK_CASE(2) MW_SK_CASE(3) MW_SK_CASE(4) MW_SK_CASE(5) MW_SK_CASE(6) MW_SK_CASE(7) MW_SK_CASE(8)
+#define MW_SK_CASE(KPW) case KPW: hipLaunchKernelGGL((gemv_splitk_kernel<MT, KPW, R, W8>), grid, block, 0, s, p, ks_per); return true;
+        MW_SK_CASE(1) MW_SK_CASE(2) MW_SK_CASE(3) MW_SK_CASE(4)
 #undef MW_SK_CASE
-        default: return false;
+        default: break;
     }
+    if constexpr (!W8) {
+        switch (kpw) {
+#define MW_SK_CASE(KPW) case KPW: hipLaunchKernelGGL((gemv_splitk_kernel<MT, KPW, R, false>), grid, block, 0, s, p, ks_per); return true;
+            MW_SK_CASE(5) MW_SK_CASE(6) MW_SK_CASE(7) MW_SK_CASE(8)
+#undef MW_SK_CASE
+            default: break;
+        }
+    }
+    return false;
 }
 
 // Residual projection with K >= 2N (the MLP's second matrix): 32-row groups and as many K ranges as
@@ -917,11 +1015,13 @@ bool launch_splitk_r(const GemvParams& p, int S, hipStream_t s) {
 // Returns false when the shape does not fit; the plain kernel takes over.
 bool launch_splitk(const GemvParams& p, int mt, hipStream_t s) {
     static const bool off = getenv("MW_SPLITK_OFF") != nullptr;
-    if (off || !p.sk_partial || !p.sk_tickets || p.K % 32 || p.K < 2 * p.N || p.N % 32) return false;
+    const int kstep = p.W8 ? 64 : 32;
+    if (off || !p.sk_partial || !p.sk_tickets || p.K % kstep || p.K < 2 * p.N || p.N % 32) return false;
     const int groups = p.N / 32;
-    const int S = max(1, min(240 / groups, min(kSplitKMax, p.K / 32)));
+    const int S = max(1, min(240 / groups, min(kSplitKMax, p.K / kstep)));
     if (groups > p.sk_groups || (long)groups * S * 2 * mt * 256 > p.sk_partial_floats) return false;
-    return mt == 1 ? launch_splitk_r<1, 2>(p, S, s) : launch_splitk_r<2, 2>(p, S, s);
+    if (p.W8) return mt == 1 ? launch_splitk_r<1, 2, true>(p, S, s) : launch_splitk_r<2, 2, true>(p, S, s);
+    return mt == 1 ? launch_splitk_r<1, 2, false>(p, S, s) : launch_splitk_r<2, 2, false>(p, S, s);
 }
 
 }  // namespace
@@ -947,7 +1047,8 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
     if (p.ln_g && p.nv == 16 && p.N > 256 * 16 && p.N <= 256 * 32)        // at most one workgroup per CU
         p.nv = ((p.N + 255) / 256 + 3) / 4 * 4;
     if (p.out_mode == GV_RESID && !p.ln_g && launch_splitk(p, mt, s)) return;
-    if (mt == 1) (void)launch_gemv_mt<1>(p, s); else (void)launch_gemv_mt<2>(p, s);
+    if (p.W8) { if (mt == 1) (void)launch_gemv_mt<1, true>(p, s); else (void)launch_gemv_mt<2, true>(p, s); }
+    else { if (mt == 1) (void)launch_gemv_mt<1, false>(p, s); else (void)launch_gemv_mt<2, false>(p, s); }
 }
 
 template <int RPT>

@@ -63,6 +63,72 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// e4m3 (OCP, max 448) pair conversion: round to nearest even in hardware; the inputs are clamped
+// to the finite range first so that no overflow encoding can appear.
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
+// LayerNorm whose output feeds an fp8 product: the normalised row is quantised to e4m3 with one
+// scale per row, scale = max|y| / 448 (1 for an all-zero row), y8 = round(y / scale).  Same
+// statistics as layernorm_kernel; the row never leaves the registers.
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ b, uint8_t* __restrict__ y8,
+                                                            float* __restrict__ yscale, float* __restrict__ y32, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * D;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            v[i] = *reinterpret_cast<const float4*>(xr + c);
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + 1e-5f);
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + c);
+            const float4 bb = *reinterpret_cast<const float4*>(b + c);
+            v[i].x = v[i].x * rstd * gg.x + bb.x; v[i].y = v[i].y * rstd * gg.y + bb.y;
+            v[i].z = v[i].z * rstd * gg.z + bb.z; v[i].w = v[i].w * rstd * gg.w + bb.w;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+            if (y32) *reinterpret_cast<float4*>(y32 + (long)row * D + c) = v[i];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float sc = mx > 0.f ? mx / 448.f : 1.f;
+    if (lane == 0) yscale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D)
+            *reinterpret_cast<unsigned*>(y8 + (long)row * D + c) = pack4_e4m3(v[i].x / sc, v[i].y / sc, v[i].z / sc, v[i].w / sc);
+    }
+}
+
 __global__ void bcast_rows_kernel(const float* __restrict__ table, float* __restrict__ x, long per_batch, long total) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i < total) *reinterpret_cast<float4*>(x + i) = *reinterpret_cast<const float4*>(table + (i % per_batch));
@@ -291,11 +357,65 @@ __global__ void conv_permute_kernel(const void* __restrict__ src, int dt, f16* _
     dst[i] = (f16)load_as_f32(src, dt, ((long)d * C + c) * 3 + j);
 }
 
+// fp8 weight import: one workgroup per weight row; scale = max|w| / 448 per row (1 for a zero row),
+// w8 = round_to_e4m3(w / scale).  cols is a multiple of 4.
+__global__ __launch_bounds__(256) void quant_rows_kernel(const void* __restrict__ src, int dt, uint8_t* __restrict__ dst,
+                                                         float* __restrict__ scale, int cols) {
+    __shared__ float red[4];
+    const long base = (long)blockIdx.x * cols;
+    const int tid = threadIdx.x;
+    float mx = 0.f;
+    for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, fabsf(load_as_f32(src, dt, base + c)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = mx > 0.f ? mx / 448.f : 1.f;
+    if (tid == 0) scale[blockIdx.x] = sc;
+    for (int c = tid * 4; c < cols; c += 1024)
+        *reinterpret_cast<unsigned*>(dst + base + c) =
+            pack4_e4m3(load_as_f32(src, dt, base + c) / sc, load_as_f32(src, dt, base + c + 1) / sc,
+                       load_as_f32(src, dt, base + c + 2) / sc, load_as_f32(src, dt, base + c + 3) / sc);
+}
+
+// e4m3 bytes -> the same values in fp16 (every e4m3 value is an fp16 value): 16 elements per thread
+__global__ __launch_bounds__(256) void fp8_to_f16_kernel(const uint8_t* __restrict__ src, f16* __restrict__ dst, long n16) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const uint4 w = *reinterpret_cast<const uint4*>(src + i * 16);
+    const unsigned u[4] = {w.x, w.y, w.z, w.w};
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    half2v h[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        h[2 * d] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u[d], 1.0f, false);
+        h[2 * d + 1] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(u[d], 1.0f, true);
+    }
+    uint4* o = reinterpret_cast<uint4*>(dst + i * 16);
+    o[0] = *reinterpret_cast<uint4*>(&h[0]);
+    o[1] = *reinterpret_cast<uint4*>(&h[4]);
+}
+
 }  // namespace
 
 void launch_layernorm(const float* x, const float* g, const float* b, f16* y, float* y32, int rows, int D, hipStream_t s,
                       int* advance) {
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, y32, rows, D, advance);
+}
+
+void launch_layernorm_fp8(const float* x, const float* g, const float* b, uint8_t* y8, float* yscale, float* y32, int rows, int D,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y8, yscale, y32, rows, D);
+}
+
+void launch_quant_rows(const void* src, int src_dtype, uint8_t* dst, float* scale, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(quant_rows_kernel, dim3(rows), dim3(256), 0, s, src, src_dtype, dst, scale, cols);
+}
+
+void launch_fp8_to_f16(const uint8_t* src, f16* dst, long n, hipStream_t s) {
+    const long n16 = n / 16;
+    hipLaunchKernelGGL(fp8_to_f16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, src, dst, n16);
 }
 
 void launch_bcast_rows(const float* table, float* x, int B, int rows, int D, hipStream_t s) {

@@ -18,6 +18,15 @@
 // A and C rows may be "batched with gaps": row m lives at (m / rows_per_batch) * batch_stride +
 // (m % rows_per_batch) * ld.  With ld smaller than K consecutive rows overlap, which is how the
 // k=3 convolutions of the encoder stem run as plain GEMMs over a time-major padded buffer.
+//
+// F8 form (both operands OCP e4m3, one byte per element): the staging code is the f16 code run on
+// "pseudo halfs" (the launcher halves K and the leading dimensions, so a 128-byte tile row is 128
+// fp8 elements instead of 64 halfs); only the MFMA and the epilogue differ.  A lane's two 16-byte
+// fragments of a tile row go to ONE v_mfma_f32_16x16x128_f8f6f4 (the gfx950 form that runs fp8 at
+// twice the f16 rate; zero scale operands select its unscaled encoding): which k a fragment byte
+// stands for is irrelevant as long as both operands are read through the same (row, chunk) map,
+// which they are.  The accumulator then holds the integer-exact sum of e4m3 products; the epilogue
+// multiplies by the activation row's scale and the weight row's scale before the bias.
 #include "mw_kernels.h"
 
 #include <stdlib.h>
@@ -28,6 +37,19 @@ namespace mw {
 namespace {
 
 constexpr int BN = 128, BK = 64;
+
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int8v __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float4v mfma_f16(int4v a, int4v b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+// 128 fp8 (e4m3) products per output element: a lane passes 32 bytes of its row per operand
+__device__ __forceinline__ float4v mfma_f8(int4v a0, int4v a1, int4v b0, int4v b1, float4v c) {
+    const int8v a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const int8v b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) {      // offset in halfs inside a [rows][64] tile
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
@@ -51,10 +73,12 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // Fused epilogue: lane holds C[m][n..n+3], m = m0 + wm*MI*16 + j*16 + fr, n = n0 + wn*64 + i*16 + 4*fg.
 // Output mode and GELU are compile-time here (one uniform switch at the call site): the unrolled
 // MI x 4 body must stay small, or instruction fetch dominates the tile.
-template <int MI, int OUT, bool GELU>
+// SC: 0 = no scales; 1 = columns scaled by w_scale[n] (fp16 product over unscaled weight codes);
+// 2 = a_scale[m] * w_scale[n] (fp8 product).
+template <int MI, int OUT, bool GELU, int SC = 0>
 __device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, float4v (&acc)[4][MI], int m0, int n0, int wm, int wn,
                                                 int fr, int fg) {
-    float4 bv[4];
+    float4 bv[4], wsc[4];
     float sc[4];
     bool n_ok[4];
     long col[4];            // column part of the output offset
@@ -65,6 +89,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, float4v (&a
         n_ok[i] = n < p.N;                              // N is a multiple of 4
         const int nc = n_ok[i] ? n : 0;
         bv[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (SC > 0) wsc[i] = *reinterpret_cast<const float4*>(p.w_scale + nc);
         sc[i] = n < p.scale_ncols ? p.scale : 1.0f;
         if constexpr (OUT == OUT_F16 || OUT == OUT_RESID_F32) {
             col[i] = nc; sec[i] = 0;
@@ -81,6 +106,8 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, float4v (&a
     for (int j = 0; j < MI; ++j) {
         const int m = m0 + wm * MI * 16 + j * 16 + fr;
         const bool m_ok = m < p.M;
+        float asc = 1.f;
+        if constexpr (SC == 2) asc = p.a_scale[m_ok ? m : 0];
         long row, rowT = 0;     // row part of the output offset (rowT: the same for the transposed V)
         if constexpr (OUT == OUT_F16 || OUT == OUT_RESID_F32) {
             row = flat ? (long)m * p.ldc : (long)(m / p.c_rows_per_batch) * p.c_batch_stride + (long)(m % p.c_rows_per_batch) * p.ldc;
@@ -93,6 +120,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, float4v (&a
         for (int i = 0; i < 4; ++i) {
             if (!(m_ok && n_ok[i])) continue;
             float4v v = acc[i][j];
+            if constexpr (SC > 0) { v[0] *= asc * wsc[i].x; v[1] *= asc * wsc[i].y; v[2] *= asc * wsc[i].z; v[3] *= asc * wsc[i].w; }
             v[0] = (v[0] + bv[i].x) * sc[i]; v[1] = (v[1] + bv[i].y) * sc[i];
             v[2] = (v[2] + bv[i].z) * sc[i]; v[3] = (v[3] + bv[i].w) * sc[i];
             if constexpr (GELU) { v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]); }
@@ -117,9 +145,21 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, float4v (&a
     }
 }
 
-template <int MI>
+template <int MI, bool F8 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc)[4][MI], int m0, int n0, int wm, int wn, int fr,
                                               int fg) {
+    if constexpr (F8) {         // the three products that run in fp8: encoder QKV, MLP in (GELU), cross K/V
+        switch (p.out_mode) {
+            case OUT_F16: gemm_epilogue_t<MI, OUT_F16, true, 2>(p, acc, m0, n0, wm, wn, fr, fg); break;
+            case OUT_QKV_SPLIT: gemm_epilogue_t<MI, OUT_QKV_SPLIT, false, 2>(p, acc, m0, n0, wm, wn, fr, fg); break;
+            default: gemm_epilogue_t<MI, OUT_KV_SPLIT, false, 2>(p, acc, m0, n0, wm, wn, fr, fg); break;
+        }
+        return;
+    }
+    if (p.w_scale) {            // fp16 product over fp8 weight codes expanded to fp16: the residual projections
+        gemm_epilogue_t<MI, OUT_RESID_F32, false, 1>(p, acc, m0, n0, wm, wn, fr, fg);
+        return;
+    }
     switch (p.out_mode) {
         case OUT_F16:
             if (p.gelu) gemm_epilogue_t<MI, OUT_F16, true>(p, acc, m0, n0, wm, wn, fr, fg);
@@ -134,7 +174,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
     }
 }
 
-template <int MI, bool GLDS>
+template <int MI, bool GLDS, bool F8 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     constexpr int BM = MI * 32;
     constexpr int STAGE = (BM + BN) * BK;                        // halfs per buffer: A tile then W tile
@@ -174,18 +214,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     auto compute = [&](int buf) {
         const f16* at = lds + buf * STAGE;
         const f16* wt = at + BM * BK;
+        if constexpr (F8) {
+            int4v wf[4][2], af[MI][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8 wf[4], af[MI];
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const half8*>(&wt[swz(wn * 64 + i * 16 + fr, ks * 4 + fg)]);
+                for (int i = 0; i < 4; ++i) wf[i][ks] = *reinterpret_cast<const int4v*>(&wt[swz(wn * 64 + i * 16 + fr, ks * 4 + fg)]);
 #pragma unroll
-            for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const half8*>(&at[swz(wm * MI * 16 + j * 16 + fr, ks * 4 + fg)]);
+                for (int j = 0; j < MI; ++j) af[j][ks] = *reinterpret_cast<const int4v*>(&at[swz(wm * MI * 16 + j * 16 + fr, ks * 4 + fg)]);
+            }
 #pragma unroll
             for (int j = 0; j < MI; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][j] = mfma_f8(wf[i][0], wf[i][1], af[j][0], af[j][1], acc[i][j]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 wf[4], af[MI];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const half8*>(&wt[swz(wn * 64 + i * 16 + fr, ks * 4 + fg)]);
+#pragma unroll
+                for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const half8*>(&at[swz(wm * MI * 16 + j * 16 + fr, ks * 4 + fg)]);
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -271,20 +326,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             __syncthreads();
         }
     }
-    gemm_epilogue<MI>(p, acc, m0, n0, wm, wn, fr, fg);
+    gemm_epilogue<MI, F8>(p, acc, m0, n0, wm, wn, fr, fg);
 }
 
-template <int MI, bool GLDS>
+template <int MI, bool GLDS, bool F8 = false>
 void launch_t(const GemmParams& p, hipStream_t s) {
     constexpr int BM = MI * 32;
     constexpr size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(f16);
     static bool prepared = false;
     if (!prepared) {      // raise the dynamic-LDS limit once (first use is never inside stream capture: the encoder runs first)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MI, GLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MI, GLDS, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         prepared = true;
     }
     const int nt = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_kernel<MI, GLDS>), dim3(nt), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_kernel<MI, GLDS, F8>), dim3(nt), dim3(256), lds, s, p);
 }
 
 // ------------------------------------------------------------------ 256x256x64 tile, 8 waves
@@ -316,6 +371,7 @@ __device__ __forceinline__ void wait_vm() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+template <bool F8>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) f16 lds[];   // [2 K-tiles][4 half-tiles][128][64], the only LDS object
     const int tid = threadIdx.x, lane = tid & 63;
@@ -365,19 +421,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int sx = (fr >> 1) & 7;
     const int a_off0 = (wr * 64 + fr) * BK + ((fg ^ sx) << 3);          // + j*16*BK; k-step 1: chunk ^ 4
     const int b_off0 = (wc * 32 + fr) * BK + ((fg ^ sx) << 3);
-    half8 af[4][2], b0f[2][2], b1f[2][2];
+    // fragments of both k-steps of a tile row: 8 registers per (sub)tile, the f16 form uses them as two
+    // 4-register operands, the fp8 form as one 8-register operand
+    int8v af[4], b0f[2], b1f[2];
     auto read_a = [&](const f16* slot) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            af[j][0] = *reinterpret_cast<const half8*>(slot + a_off0 + j * 16 * BK);
-            af[j][1] = *reinterpret_cast<const half8*>(slot + (a_off0 ^ 32) + j * 16 * BK);
+            af[j].lo = *reinterpret_cast<const int4v*>(slot + a_off0 + j * 16 * BK);
+            af[j].hi = *reinterpret_cast<const int4v*>(slot + (a_off0 ^ 32) + j * 16 * BK);
         }
     };
-    auto read_b = [&](const f16* slot, half8 (&bf)[2][2]) {
+    auto read_b = [&](const f16* slot, int8v (&bf)[2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            bf[i][0] = *reinterpret_cast<const half8*>(slot + b_off0 + i * 16 * BK);
-            bf[i][1] = *reinterpret_cast<const half8*>(slot + (b_off0 ^ 32) + i * 16 * BK);
+            bf[i].lo = *reinterpret_cast<const int4v*>(slot + b_off0 + i * 16 * BK);
+            bf[i].hi = *reinterpret_cast<const int4v*>(slot + (b_off0 ^ 32) + i * 16 * BK);
         }
     };
     float4v acc[4][8];   // [n subtile][m subtile]
@@ -385,17 +443,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
-    auto quadrant = [&](auto hac, auto hbc, half8 (&bf)[2][2]) {
+    auto quadrant = [&](auto hac, auto hbc, int8v (&bf)[2]) {
         constexpr int HA = decltype(hac)::value, HB = decltype(hbc)::value;
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        if constexpr (F8) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     acc[HB * 2 + i][HA * 4 + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[i][ks], af[j][ks], acc[HB * 2 + i][HA * 4 + j], 0, 0, 0);
+                        __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[i], af[j], acc[HB * 2 + i][HA * 4 + j], 0, 0, 0, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[HB * 2 + i][HA * 4 + j] = mfma_f16(bf[i].lo, af[j].lo, acc[HB * 2 + i][HA * 4 + j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[HB * 2 + i][HA * 4 + j] = mfma_f16(bf[i].hi, af[j].hi, acc[HB * 2 + i][HA * 4 + j]);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -449,30 +518,46 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     ktile(I0{}, I1{}, nk - 2);
     ktile(I1{}, std::integral_constant<int, 2>{}, nk - 1);
     if (wr == 0) __builtin_amdgcn_s_barrier();       // same barrier count for every wave
-    gemm_epilogue<8>(p, acc, m0, n0, wr, wc, fr, fg);
+    gemm_epilogue<8, F8>(p, acc, m0, n0, wr, wc, fr, fg);
 }
 
+template <bool F8>
 void launch_256(const GemmParams& p, hipStream_t s) {
     constexpr size_t lds = (size_t)8 * kHalfSlot * sizeof(f16);     // 128 KiB
     static bool prepared = false;
     if (!prepared) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         prepared = true;
     }
     const int nt = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    hipLaunchKernelGGL(gemm256_kernel, dim3(nt), dim3(512), lds, s, p);
+    hipLaunchKernelGGL(gemm256_kernel<F8>, dim3(nt), dim3(512), lds, s, p);
 }
 
 }  // namespace
 
-void launch_gemm(const GemmParams& p, hipStream_t s) {
+void launch_gemm(const GemmParams& p0, hipStream_t s) {
+    if (p0.f8) {
+        // fp8 operands: one byte per element.  Re-express the problem in 2-byte units for the staging code
+        // (the launcher's callers guarantee K % 128 == 0 and even leading dimensions).
+        GemmParams p = p0;
+        p.K /= 2; p.lda /= 2; p.ldw /= 2; p.a_batch_stride /= 2;
+        const int nk = p.K / BK;
+        const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        // The 256x256 form needs 8-register operand tuples on top of the f16 form's 246 VGPRs and spills inside
+        // its K loop (743 against 993 TFLOP/s for the 128x128 form at M=24000, N=3840, K=1280): opt-in only.
+        static const bool use256 = getenv("MW_GEMM_F8_256") != nullptr;
+        if (use256 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256) launch_256<true>(p, s);
+        else launch_t<4, true, true>(p, s);
+        return;
+    }
+    const GemmParams& p = p0;
     // MI = 8 (256-row tile, one workgroup per CU) measured 35 % slower than MI = 4 (two per CU): with a
     // single barrier-synchronised workgroup on a CU nothing covers its waits.
     static const bool no256 = getenv("MW_GEMM_NO256") != nullptr;
     const int nk = p.K / BK;
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (p.K % BK != 0) launch_t<4, false>(p, s);
-    else if (!no256 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256) launch_256(p, s);
+    else if (!no256 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256) launch_256<false>(p, s);
     else launch_t<4, true>(p, s);
 }
 

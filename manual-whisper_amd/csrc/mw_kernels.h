@@ -50,6 +50,11 @@ struct GemmParams {
     void* C; long ldc; int c_rows_per_batch; long c_batch_stride;   // OUT_F16 / OUT_RESID_F32
     f16* q; f16* k; f16* v;   // split modes: q,k [B][H][T][64]; v is [B][H][64][Tpad] (QKV) or [B][H][T][64] (KV)
     int T, Tpad, H, D;
+    // f8 != 0: A and W hold OCP e4m3 bytes (lda, ldw, K still count elements; K % 128 == 0) and the
+    // product is scaled by a_scale[m] * w_scale[n] before the bias.  Output modes: OUT_F16 with GELU,
+    // OUT_QKV_SPLIT, OUT_KV_SPLIT.  f8 == 0 with w_scale != null: fp16 operands, columns scaled by
+    // w_scale[n] before the bias (W holds unscaled fp8 codes expanded to fp16); OUT_RESID_F32 without GELU only.
+    int f8; const float* a_scale; const float* w_scale;
 };
 void launch_gemm(const GemmParams& p, hipStream_t s);
 
@@ -57,12 +62,20 @@ void launch_gemm(const GemmParams& p, hipStream_t s);
 // `advance` (optional): an int in device memory that the launch increments by one when it is done
 void launch_layernorm(const float* x, const float* g, const float* b, f16* y, float* y32, int rows, int D, hipStream_t s,
                       int* advance = nullptr);
+// LayerNorm with an fp8 (OCP e4m3) result: y8 [rows][D] bytes and one scale per row (y = y8 * yscale[row]);
+// y32 (optional) receives the unquantised fp32 rows
+void launch_layernorm_fp8(const float* x, const float* g, const float* b, uint8_t* y8, float* yscale, float* y32, int rows, int D,
+                          hipStream_t s);
 void launch_bcast_rows(const float* table, float* x, int B, int rows, int D, hipStream_t s);   // x[b][r][:] = table[r][:]
 // q,k [B][H][T][64], vT [B][H][64][Tpad] -> out [B*T][H*64] fp16
 void launch_enc_attention(const f16* q, const f16* k, const f16* vT, f16* out, int B, int H, int T, int Tpad, hipStream_t s);
 
 // ---------------------------------------------------------------- weight import
 void launch_convert(const void* src, int src_dtype, void* dst, int dst_is_f16, long n, hipStream_t s);
+// fp8 weight import: [rows][cols] of any dtype -> e4m3 bytes + one scale per row (cols % 4 == 0)
+void launch_quant_rows(const void* src, int src_dtype, uint8_t* dst, float* scale, int rows, int cols, hipStream_t s);
+// e4m3 bytes -> the same values as fp16, unscaled (n % 16 == 0)
+void launch_fp8_to_f16(const uint8_t* src, f16* dst, long n, hipStream_t s);
 // conv weight [D][C][3] (any dtype) -> fp16 [D][3][C]
 void launch_conv_permute(const void* src, int src_dtype, f16* dst, int D, int C, hipStream_t s);
 
@@ -79,7 +92,9 @@ struct DecState {          // lives in device memory; one per context
 enum GemvOut { GV_F16 = 0, GV_RESID = 1, GV_QKV = 2, GV_LOGITS = 3 };
 struct GemvParams {
     int B, N, K;
-    const f16* W;             // [N][K]
+    const f16* W;             // [N][K] fp16 ...
+    const uint8_t* W8;        // ... or, when non-null, [N][K] OCP e4m3 codes with w_scale [N] (K % 64 == 0); not for GV_LOGITS
+    const float* w_scale;
     const float* bias;        // [N] or null
     // input: LayerNorm(x32; ln_g, ln_b) when ln_g != null, else xin16
     const float* x32; const float* ln_g; const float* ln_b;

@@ -13,6 +13,8 @@ Differences that cannot be avoided offline, all stated where they bite:
     windows of at most 30 s by vad.py (energy detector + whisperx's hysteresis / merge rules; the
     neural VAD model does not exist offline); ``vad_options=None`` or ``{"vad_method": "fixed"}``
     gives fixed 30 s chunks.
+  * ``compute_type``: ``"float16"`` or ``"float8"`` (the reference's CPU default ``"int8"`` is a CTranslate2 format
+    with no counterpart here).
   * decoding is greedy by default (what the throughput figures are quoted on); ``asr_options={"beam_size": 5}``
     switches to beam search at temperature 0 (whisperx's default beam; no temperature fallback), which runs
     ``max_batch // beam_size`` chunks per pass.  No timestamps; text needs tokenizer.json, otherwise a segment's text is
@@ -33,6 +35,7 @@ from .scheduler import EnginePool, batches_of, split_chunks
 
 _GPU_NAMES = ("cuda", "hip", "gpu", "rocm")
 _FP16_NAMES = ("float16", "fp16", "half", "default")
+_FP8_NAMES = ("float8", "fp8", "float8_e4m3", "float8_e4m3fn")
 
 
 def _dims_from_config(path: str) -> WhisperDims:
@@ -142,8 +145,9 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
     """
     if device not in _GPU_NAMES:
         raise EngineError(f"device={device!r}: this engine runs on an MI355X GPU only (use 'cuda'); there is no CPU path")
-    if compute_type not in _FP16_NAMES:
-        raise EngineError(f"compute_type={compute_type!r} is not available: weights are fp16 with fp32 accumulation ('float16')")
+    if compute_type not in _FP16_NAMES + _FP8_NAMES:
+        raise EngineError(f"compute_type={compute_type!r} is not available: 'float16' (fp16 weights, fp32 accumulation) or "
+                          "'float8' (e4m3 Linear weights with a scale per output row, quantised at load)")
     if task != "transcribe":
         raise EngineError("only task='transcribe' is implemented")
     asr_options = dict(asr_options or {})
@@ -174,7 +178,7 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
         if os.path.exists(tok):
             from tokenizers import Tokenizer
             tokenizer = Tokenizer.from_file(tok)
-    engine = Engine(dims, device=device_index, max_batch=max_batch)
+    engine = Engine(dims, device=device_index, max_batch=max_batch, weight_format="fp8" if compute_type in _FP8_NAMES else "f16")
     engine.load_weights(weights)
     del weights
     return Model(engine, dims, language or "zh", tokenizer, asr_options.get("initial_prompt"), vad_options,

@@ -104,6 +104,52 @@ def log_mel(pcm: np.ndarray, n_mels: int) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------
+# fp8 (OCP e4m3fn) weight format
+# ----------------------------------------------------------------------------
+# BASELINE config 5 asks for "fp8 weights (CDNA4 fp8 MFMA)".  Neither the reference (CTranslate2 has
+# no fp8 type; transcribe.py:32 uses its int8) nor Hugging Face Whisper defines such a path, so the
+# scheme is this build's own and PARITY WITH THE REFERENCE IS UNPINNED for it.  What is pinned: the
+# e4m3 rounding below agrees with torch.float8_e4m3fn on every finite input tried
+# (tests/test_oracle.py), and the HIP engine must reproduce THIS restatement.
+#   weights:     per output row, scale = max|w| / 448 (1 for a zero row), code = rne_e4m3(w / scale);
+#                the Linear weights of the encoder and decoder layers only.
+#   activations: the rows a LayerNorm hands to an encoder Linear (QKV, MLP in) and the encoder output
+#                rows handed to the cross K/V projection are quantised the same way, one scale per row.
+E4M3_MAX = np.float32(448.0)
+
+
+def e4m3_round(x: np.ndarray) -> np.ndarray:
+    """Nearest OCP e4m3fn value (as float32), ties to even, saturating at +-448.
+
+    e4m3fn: 1 sign, 4 exponent (bias 7), 3 mantissa bits; normals 2^-6 .. 448, subnormals k * 2^-9.
+    """
+    x = np.asarray(x, dtype=np.float32)
+    a = np.minimum(np.abs(x), E4M3_MAX)
+    _, e = np.frexp(a)                                   # a = m * 2^e, m in [0.5, 1)
+    e = np.maximum(e - 1, -6)                            # exponent of the leading bit, subnormal range pinned to -6
+    step = np.ldexp(np.float32(1.0), e - 3)              # spacing of representable values in that binade
+    return np.copysign((np.rint(a / step) * step).astype(np.float32), x)
+
+
+def quantize_rows_e4m3(x: np.ndarray):
+    """Per-row (last axis) e4m3 quantisation: -> (codes as float32 values, scales float32 [..., 1])."""
+    x = np.asarray(x, dtype=np.float32)
+    amax = np.abs(x).max(axis=-1, keepdims=True)
+    scale = np.where(amax > 0, amax / E4M3_MAX, np.float32(1.0)).astype(np.float32)
+    return e4m3_round((x / scale).astype(np.float32)), scale
+
+
+def fake_quant_rows_e4m3(x: np.ndarray) -> np.ndarray:
+    q, s = quantize_rows_e4m3(x)
+    return (q * s).astype(np.float32)
+
+
+def is_fp8_weight(name: str) -> bool:
+    """The tensors an fp8 engine stores as e4m3: Linear weights inside encoder / decoder layers."""
+    return ".layers." in name and name.endswith(".weight") and (name.endswith("_proj.weight") or ".fc1." in name or ".fc2." in name)
+
+
+# ----------------------------------------------------------------------------
 # transformer pieces
 # ----------------------------------------------------------------------------
 _erf = np.vectorize(math.erf, otypes=[np.float64])
@@ -155,9 +201,16 @@ class WhisperOracle:
     ``model.decoder.embed_tokens.weight`` — modeling_whisper.py:965,970,1080).
     """
 
-    def __init__(self, dims, weights: dict):
+    def __init__(self, dims, weights: dict, weight_format: str = "f16"):
+        assert weight_format in ("f16", "fp8")
         self.d = dims
         self.w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
+        self.fp8 = weight_format == "fp8"
+        if self.fp8:
+            for k in self.w:
+                if is_fp8_weight(k):
+                    self.w[k] = fake_quant_rows_e4m3(self.w[k])
+        self._q = fake_quant_rows_e4m3 if self.fp8 else (lambda a: a)      # activation rows ahead of an fp8 product
         self.H = dims.n_heads
         self.scale = np.float32((dims.d_model // dims.n_heads) ** -0.5)
 
@@ -197,10 +250,10 @@ class WhisperOracle:
     def encoder_layer(self, i, x):
         w = self.w
         p = f"model.encoder.layers.{i}"
-        h = layer_norm(x, w[p + ".self_attn_layer_norm.weight"], w[p + ".self_attn_layer_norm.bias"])
+        h = self._q(layer_norm(x, w[p + ".self_attn_layer_norm.weight"], w[p + ".self_attn_layer_norm.bias"]))
         q, k, v = self._attn_proj(p + ".self_attn", h, h)
         x = x + self._attn_core(p + ".self_attn", q, k, v)
-        h = layer_norm(x, w[p + ".final_layer_norm.weight"], w[p + ".final_layer_norm.bias"])
+        h = self._q(layer_norm(x, w[p + ".final_layer_norm.weight"], w[p + ".final_layer_norm.bias"]))
         h = gelu(linear(h, w[p + ".fc1.weight"], w[p + ".fc1.bias"]))
         return (x + linear(h, w[p + ".fc2.weight"], w[p + ".fc2.bias"])).astype(np.float32)
 
@@ -216,6 +269,7 @@ class WhisperOracle:
         """Per decoder layer (K, V) over the encoder output, computed once (:321-335)."""
         out = []
         w = self.w
+        enc = self._q(enc)
         for i in range(self.d.dec_layers):
             p = f"model.decoder.layers.{i}.encoder_attn"
             k = _split_heads(linear(enc, w[p + ".k_proj.weight"]), self.H)

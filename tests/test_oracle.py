@@ -81,3 +81,54 @@ def test_synth_numpy_equals_torch():
     b = synth.make_weights_torch(dims, 99)
     for k in a:
         assert (a[k] == b[k].float().numpy()).all(), k
+
+
+# ---------------------------------------------------------------------------------------------
+# fp8 (e4m3) weight format of the oracle
+# ---------------------------------------------------------------------------------------------
+def test_e4m3_rounding_agrees_with_torch_float8():
+    """The oracle's e4m3 rounding against torch.float8_e4m3fn: every code, every midpoint between
+    neighbouring codes (ties to even), random values over the whole range, saturation at 448."""
+    import torch
+    from oracle.whisper_ref import e4m3_round
+    codes = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float().numpy()
+    fin = np.unique(codes[np.isfinite(codes)])
+    assert fin.size == 253 and fin.max() == 448.0                 # 254 finite codes, +0 and -0 coincide
+    assert (e4m3_round(fin) == fin).all()
+    mid = ((fin[1:] + fin[:-1]) / 2).astype(np.float32)
+    rng = np.random.default_rng(0)
+    x = np.concatenate([mid, np.nextafter(mid, np.float32(1e9)), np.nextafter(mid, np.float32(-1e9)),
+                        rng.normal(0, 1, 50000), rng.normal(0, 120, 50000), rng.uniform(-0.03, 0.03, 50000)]).astype(np.float32)
+    x = np.clip(x, -448, 448)
+    want = torch.from_numpy(x).to(torch.float8_e4m3fn).float().numpy()
+    assert (e4m3_round(x) == want).all()
+    assert (e4m3_round(np.float32([500.0, -1e6, 448.1])) == np.float32([448, -448, 448])).all()
+
+
+def test_fp8_row_quantisation_and_weight_selection():
+    from oracle.whisper_ref import fake_quant_rows_e4m3, is_fp8_weight, quantize_rows_e4m3
+    rng = np.random.default_rng(1)
+    w = rng.normal(0, 0.02, (64, 256)).astype(np.float32)
+    w[5] = 0
+    q, s = quantize_rows_e4m3(w)
+    assert s.shape == (64, 1) and s[5, 0] == 1.0 and (q[5] == 0).all()
+    assert np.abs(q).max() == 448.0 and (np.abs(q).max(axis=1)[np.arange(64) != 5] == 448.0).all()
+    rel = np.abs(fake_quant_rows_e4m3(w) - w)[np.abs(w) > 1e-3] / np.abs(w)[np.abs(w) > 1e-3]
+    assert rel.max() <= 2.0 ** -4 + 1e-6                               # half a unit in the last of 3 mantissa bits
+    dims = mw.get_dims("micro")
+    names = synth.make_weights_np(dims, 1).keys()
+    picked = [n for n in names if is_fp8_weight(n)]
+    # per encoder layer q,k,v,out,fc1,fc2; per decoder layer those plus the four cross-attention projections
+    assert len(picked) == dims.enc_layers * 6 + dims.dec_layers * 10
+    assert not any("conv" in n or "embed" in n or "layer_norm" in n or n.endswith(".bias") for n in picked)
+
+
+def test_fp8_oracle_stays_near_the_unquantised_one():
+    from oracle.whisper_ref import WhisperOracle, log_mel
+    dims = mw.get_dims("micro")
+    w = synth.make_weights_np(dims, 1234)
+    mel = log_mel(synth.make_pcm_np(1, 3), dims.n_mels)
+    e32 = WhisperOracle(dims, w).encode(mel)
+    e8 = WhisperOracle(dims, w, weight_format="fp8").encode(mel)
+    rms = float(np.sqrt(np.mean((e8 - e32) ** 2)))
+    assert 0.01 < rms < 0.12, rms                                      # quantisation is in effect and is a perturbation

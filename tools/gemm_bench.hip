@@ -1,12 +1,15 @@
 // Developer harness: checks launch_gemm against a naive GPU product on random fp16 data and times it.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I manual-whisper_amd/csrc tools/gemm_bench.hip \
 //         manual-whisper_amd/csrc/kernels_gemm.o -o tools/gemm_bench
-//   tools/gemm_bench M N K [iters]
+//   tools/gemm_bench M N K [iters] [f8]
+// With "f8" both operands are random OCP e4m3 codes with random row scales, the epilogue is the MLP-in one
+// (scales, bias, GELU), and the reference decodes the codes in software.
 #include "mw_kernels.h"
 
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 using namespace mw;
@@ -30,14 +33,53 @@ __global__ void ref_kernel(const f16* A, const f16* W, const float* bias, float*
     C[(long)r * N + n] = s + bias[n];
 }
 
+__global__ void fill8_kernel(uint8_t* x, long n, unsigned seed) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned h = (unsigned)i ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    unsigned c = h & 0xff;
+    if ((c & 0x7f) == 0x7f) c ^= 1;          // 0x7f / 0xff are NaN in e4m3fn
+    x[i] = (uint8_t)c;
+}
+
+__device__ float e4m3_decode(uint8_t c) {       // software decode: 1-4-3, bias 7, subnormals k * 2^-9
+    const int e = (c >> 3) & 15, m = c & 7;
+    const float v = e == 0 ? ldexpf((float)m, -9) : ldexpf(1.0f + m * 0.125f, e - 7);
+    return (c & 0x80) ? -v : v;
+}
+
+__global__ void ref8_kernel(const uint8_t* A, const uint8_t* W, const float* as, const float* ws, const float* bias, float* C,
+                            int M, int N, int K, const int* rows, int nrows) {
+    const int r = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows || n >= N) return;
+    const int m = rows[r];
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += e4m3_decode(A[(long)m * K + k]) * e4m3_decode(W[(long)n * K + k]);
+    const float x = s * (as[m] * ws[n]) + bias[n];
+    C[(long)r * N + n] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 24000, N = argc > 2 ? atoi(argv[2]) : 1280, K = argc > 3 ? atoi(argv[3]) : 1280;
     const int iters = argc > 4 ? atoi(argv[4]) : 20;
-    f16 *A, *W, *C; float *bias, *Cref; int* rows_d;
+    const bool f8 = argc > 5 && !strcmp(argv[5], "f8");
+    f16 *A, *W, *C; float *bias, *Cref, *as = nullptr, *ws = nullptr; int* rows_d;
     CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 2));
     CK(hipMalloc(&bias, (size_t)N * 4));
-    fill_kernel<<<(unsigned)(((long)M * K + 255) / 256), 256>>>(A, (long)M * K, 1u, 1.0f);
-    fill_kernel<<<(unsigned)(((long)N * K + 255) / 256), 256>>>(W, (long)N * K, 2u, 0.05f);
+    if (f8) {
+        fill8_kernel<<<(unsigned)(((long)M * K + 255) / 256), 256>>>((uint8_t*)A, (long)M * K, 1u);
+        fill8_kernel<<<(unsigned)(((long)N * K + 255) / 256), 256>>>((uint8_t*)W, (long)N * K, 2u);
+        std::vector<float> ha(M), hw(N);
+        for (int i = 0; i < M; ++i) ha[i] = 0.002f + 1e-5f * (i % 97);
+        for (int i = 0; i < N; ++i) hw[i] = 0.0005f + 1e-6f * (i % 53);
+        CK(hipMalloc(&as, (size_t)M * 4)); CK(hipMalloc(&ws, (size_t)N * 4));
+        CK(hipMemcpy(as, ha.data(), (size_t)M * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(ws, hw.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    } else {
+        fill_kernel<<<(unsigned)(((long)M * K + 255) / 256), 256>>>(A, (long)M * K, 1u, 1.0f);
+        fill_kernel<<<(unsigned)(((long)N * K + 255) / 256), 256>>>(W, (long)N * K, 2u, 0.05f);
+    }
     std::vector<float> hb(N);
     for (int i = 0; i < N; ++i) hb[i] = 0.01f * (i % 17);
     CK(hipMemcpy(bias, hb.data(), (size_t)N * 4, hipMemcpyHostToDevice));
@@ -46,6 +88,7 @@ int main(int argc, char** argv) {
     p.A = A; p.lda = K; p.a_rows_per_batch = M; p.a_batch_stride = 0; p.W = W; p.ldw = K; p.M = M; p.N = N; p.K = K;
     p.bias = bias; p.scale = 1.f; p.scale_ncols = 0; p.gelu = 0; p.out_mode = OUT_F16; p.C = C; p.ldc = N;
     p.c_rows_per_batch = M; p.c_batch_stride = 0;
+    if (f8) { p.f8 = 1; p.a_scale = as; p.w_scale = ws; p.gelu = 1; }
     hipStream_t s; CK(hipStreamCreate(&s));
     launch_gemm(p, s);
     CK(hipStreamSynchronize(s));
@@ -56,7 +99,8 @@ int main(int argc, char** argv) {
     const int nrows = (int)rows.size();
     CK(hipMalloc(&rows_d, nrows * 4)); CK(hipMalloc(&Cref, (size_t)nrows * N * 4));
     CK(hipMemcpy(rows_d, rows.data(), nrows * 4, hipMemcpyHostToDevice));
-    ref_kernel<<<dim3((N + 127) / 128, nrows), 128>>>(A, W, bias, Cref, M, N, K, rows_d, nrows);
+    if (f8) ref8_kernel<<<dim3((N + 127) / 128, nrows), 128>>>((uint8_t*)A, (uint8_t*)W, as, ws, bias, Cref, M, N, K, rows_d, nrows);
+    else ref_kernel<<<dim3((N + 127) / 128, nrows), 128>>>(A, W, bias, Cref, M, N, K, rows_d, nrows);
     std::vector<float> href((size_t)nrows * N);
     std::vector<f16> hc((size_t)M * N);
     CK(hipMemcpy(href.data(), Cref, href.size() * 4, hipMemcpyDeviceToHost));
