@@ -32,7 +32,7 @@ struct mw_ctx {
     std::string err;
     std::vector<void*> allocs;
     bool finalized = false;
-    int use_graph = 1, check_every = 16;
+    int use_graph = 1, check_every = 16, use_prefill = 1;
     const mw_ctx* parent = nullptr;                       // non-null: weights and tables belong to `parent`
 
     // weights
@@ -259,7 +259,8 @@ static int alloc_work(mw_ctx* ctx) {
     ctx->n_parts = gemv_logits_parts(d.vocab);
     ALLOC(ctx->part_val, B * (size_t)ctx->n_parts); ALLOC(ctx->part_idx, B * (size_t)ctx->n_parts);
     ALLOC(ctx->mask_first, (size_t)d.vocab, true); ALLOC(ctx->mask_rest, (size_t)d.vocab, true);
-    ALLOC(ctx->xpartial, B * H * kXattnSplit * 68); ALLOC(ctx->xtickets, B * H, true);
+    const size_t xrows = std::max<size_t>(B, kPrefillSlabRows);      // query rows one cross-attention launch may carry
+    ALLOC(ctx->xpartial, xrows * H * kXattnSplit * 68); ALLOC(ctx->xtickets, xrows * H, true);
     ALLOC(ctx->skpartial, splitk_partial_floats(D)); ALLOC(ctx->sktickets, splitk_groups(D), true);
     ctx->forced_cap = d.n_text_ctx;
     ALLOC(ctx->forced, B * (size_t)ctx->forced_cap);
@@ -325,7 +326,7 @@ extern "C" int mw_fork(mw_ctx* parent, mw_ctx** out) {
     if (parent->parent) return fail(parent, MW_ERR_ARG, "mw_fork: fork from the original engine, not from a fork");
     mw_ctx* ctx = new mw_ctx();
     ctx->d = parent->d; ctx->device = parent->device; ctx->max_batch = parent->max_batch;
-    ctx->use_graph = parent->use_graph; ctx->check_every = parent->check_every;
+    ctx->use_graph = parent->use_graph; ctx->check_every = parent->check_every; ctx->use_prefill = parent->use_prefill;
     ctx->parent = parent; ctx->finalized = true;
     // shared, read-only on the hot path
     ctx->conv1_w = parent->conv1_w; ctx->conv1_b = parent->conv1_b; ctx->conv2_w = parent->conv2_w; ctx->conv2_b = parent->conv2_b;
@@ -355,6 +356,7 @@ extern "C" int mw_set_option(mw_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return MW_ERR_ARG;
     if (!strcmp(key, "graph")) ctx->use_graph = value != 0;
     else if (!strcmp(key, "check_every")) ctx->check_every = value < 1 ? 1 : value;
+    else if (!strcmp(key, "prefill")) ctx->use_prefill = value != 0;
     else return fail(ctx, MW_ERR_ARG, std::string("mw_set_option: unknown key ") + key);
     return MW_OK;
 }
@@ -722,6 +724,26 @@ extern "C" int mw_encode(mw_ctx* ctx, const float* mel, int batch, float* enc_ou
     return MW_OK;
 }
 
+// The end of a step: final LayerNorm (the same launch advances the position counter for the launches after
+// it), logits with the partial arg-max, token bookkeeping.
+static void enqueue_step_tail(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, const BeamParams* beam = nullptr) {
+    const mw_model_desc& d = ctx->d;
+    const int D = d.d_model;
+    hipStream_t s = ctx->stream;
+    launch_layernorm(ctx->dx, ctx->dec_ln.g, ctx->dec_ln.b, ctx->dxn, nullptr, B, D, s, &ctx->st->pos);
+    {
+        GemvParams p{};
+        p.B = B; p.N = d.vocab; p.K = D; p.W = ctx->tok_emb; p.scale = 1.f; p.H = d.n_heads; p.D = D; p.Tctx = d.n_text_ctx;
+        p.st = ctx->st; p.nv = 16;
+        p.xin16 = ctx->dxn; p.out_mode = GV_LOGITS; p.out32 = want_logits ? ctx->logits : nullptr;
+        p.mask_first = ctx->mask_first; p.mask_rest = ctx->mask_rest;
+        p.part_val = ctx->part_val; p.part_idx = ctx->part_idx; p.n_parts = ctx->n_parts;
+        launch_gemv(p, s);
+    }
+    if (beam) launch_beam_step(*beam, s);
+    else launch_dec_finalize(fp, B, s);
+}
+
 // One greedy step: 8 launches per layer + final norm + logits + token bookkeeping.
 static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int max_keys, const BeamParams* beam = nullptr) {
     const mw_model_desc& d = ctx->d;
@@ -765,18 +787,7 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
         }
         {   GemvParams p = base(D, F, l.fc2); p.xin16 = ctx->dhid; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
     }
-    // final LayerNorm; the same launch advances the position counter for the logits / finalize launches
-    launch_layernorm(ctx->dx, ctx->dec_ln.g, ctx->dec_ln.b, ctx->dxn, nullptr, B, D, s, &ctx->st->pos);
-    {
-        LinearW e{ctx->tok_emb, nullptr};
-        GemvParams p = base(d.vocab, D, e);
-        p.xin16 = ctx->dxn; p.out_mode = GV_LOGITS; p.out32 = want_logits ? ctx->logits : nullptr;
-        p.mask_first = ctx->mask_first; p.mask_rest = ctx->mask_rest;
-        p.part_val = ctx->part_val; p.part_idx = ctx->part_idx; p.n_parts = ctx->n_parts;
-        launch_gemv(p, s);
-    }
-    if (beam) launch_beam_step(*beam, s);
-    else launch_dec_finalize(fp, B, s);
+    enqueue_step_tail(ctx, B, want_logits, fp, beam);
 }
 
 static FinalizeParams finalize_params(mw_ctx* ctx, int n_forced) {
@@ -786,6 +797,51 @@ static FinalizeParams finalize_params(mw_ctx* ctx, int n_forced) {
     fp.tok_emb = ctx->tok_emb; fp.pos_emb = ctx->dec_pos; fp.D = ctx->d.d_model; fp.n_text_ctx = ctx->d.n_text_ctx; fp.vocab = ctx->d.vocab;
     fp.x = ctx->dx; fp.out_ids = ctx->out_ids; fp.out_len = ctx->out_len; fp.finished = ctx->finished;
     return fp;
+}
+
+// Prompt prefill: positions 0 .. P-1 of all B sequences (ids in ctx->forced) through the decoder in one pass
+// of M = B*P rows, leaving the self-attention caches filled, dx = the residual rows of position P-1 and
+// st->pos = P-1, i.e. the state of a step-by-step run just before the final LayerNorm of step P-1.
+// Borrows the encoder's workspaces (idle while decoding): x, xn, q (as the [M][3D] q|k|v rows), k (as the
+// cross-attention queries), att, hid.  Same arithmetic as the steps (fp16 operands, fp32 accumulation, fp8
+// weight codes expanded to fp16 with the row scale in the epilogue), on the GEMM kernels instead of the GEMVs.
+static int run_prefill(mw_ctx* ctx, int B, int P) {
+    const mw_model_desc& d = ctx->d;
+    const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, Tc = d.n_text_ctx;
+    const int M = B * P;
+    hipStream_t s = ctx->stream;
+    const float qscale = 1.0f / sqrtf((float)kHeadDim);
+    const size_t self_layer = (size_t)ctx->max_batch * D * Tc;
+    const size_t cross_layer = (size_t)ctx->max_batch * T * D;
+    f16* qkv = ctx->q;          // [M][3D]: 3 * P <= 1500 always (P <= 448)
+    f16* cq = ctx->k;           // [M][D]
+    auto gemm = [&](const f16* A, int K, const LinearW& w, int N) {
+        GemmParams p = gemm_base(A, K, w.w, K, M, N, K, w.b);
+        if (ctx->fp8) { launch_fp8_to_f16(w.w8, ctx->wexp, (long)N * K, s); p.W = ctx->wexp; p.w_scale = w.ws; }
+        return p;
+    };
+    launch_prefill_embed(ctx->forced, P, B, P, ctx->tok_emb, ctx->dec_pos, ctx->x, D, s);
+    for (int li = 0; li < d.dec_layers; ++li) {
+        const DecLayerW& l = ctx->dec[li];
+        launch_layernorm(ctx->x, l.ln1.g, l.ln1.b, ctx->xn, nullptr, M, D, s);
+        {   GemmParams p = gemm(ctx->xn, D, l.qkv, 3 * D); p.scale = qscale; p.scale_ncols = D; p.C = qkv; p.ldc = 3 * D; launch_gemm(p, s); }
+        launch_prefill_self_attn(qkv, ctx->selfK + li * self_layer, ctx->selfV + li * self_layer, ctx->att, B, H, P, Tc, D, s);
+        {   GemmParams p = gemm(ctx->att, D, l.out, D); p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D; launch_gemm(p, s); }
+        launch_layernorm(ctx->x, l.ln2.g, l.ln2.b, ctx->xn, nullptr, M, D, s);
+        {   GemmParams p = gemm(ctx->xn, D, l.cq, D); p.scale = qscale; p.scale_ncols = D; p.C = cq; p.ldc = D; launch_gemm(p, s); }
+        for (int r0 = 0; r0 < M; r0 += kPrefillSlabRows) {
+            const int rows = std::min(kPrefillSlabRows, M - r0);
+            launch_dec_cross_attn(cq + (size_t)r0 * D, ctx->crossK + li * cross_layer, ctx->crossV + li * cross_layer,
+                                  ctx->att + (size_t)r0 * D, rows, H, T, ctx->xpartial, ctx->xtickets, s, P, r0);
+        }
+        {   GemmParams p = gemm(ctx->att, D, l.co, D); p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D; launch_gemm(p, s); }
+        launch_layernorm(ctx->x, l.ln3.g, l.ln3.b, ctx->xn, nullptr, M, D, s);
+        {   GemmParams p = gemm(ctx->xn, D, l.fc1, F); p.gelu = 1; p.C = ctx->hid; p.ldc = F; launch_gemm(p, s); }
+        {   GemmParams p = gemm(ctx->hid, F, l.fc2, D); p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D; launch_gemm(p, s); }
+    }
+    launch_prefill_last_rows(ctx->x, ctx->dx, B, P, D, ctx->st, s);
+    HIPCHK(hipGetLastError());
+    return MW_OK;
 }
 
 // Capture (or re-use) the graph of one step for this batch size / forced length / logits flag and the
@@ -819,7 +875,18 @@ static int run_decode(mw_ctx* ctx, int B, int n_forced, int max_new, float* logi
     const size_t row = (size_t)B * d.vocab;
     int host_fin = 0;
     int steps_run = 0;
-    for (int step = 0; step < n_steps; ++step) {       // step feeds position `step`: step + 1 cached keys
+    int first_step = 0;
+    // kv_div == 1 means "own cache" to the cross-attention launcher, so a single-row prompt keeps stepping
+    if (ctx->use_prefill && !logits_every_step && max_new > 0 && n_forced >= 2) {
+        int r = run_prefill(ctx, B, n_forced);              // positions 0 .. n_forced-1 in one pass
+        if (r) return r;
+        enqueue_step_tail(ctx, B, want_logits, fp);         // logits of the last prompt position choose the first sampled token
+        HIPCHK(hipGetLastError());
+        if (want_logits) HIPCHK(hipMemcpyAsync(logits_out, ctx->logits, row * 4, hipMemcpyDefault, s));
+        first_step = n_forced;
+        steps_run = n_forced;
+    }
+    for (int step = first_step; step < n_steps; ++step) {       // step feeds position `step`: step + 1 cached keys
         if (graph) {
             hipGraphExec_t g;
             int r = ensure_graph(ctx, B, want_logits, fp, B * 1024 + n_forced, step + 1, &g);

@@ -542,7 +542,10 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
     long bh_kv = bh;
     if constexpr (IND || GRP) {         // compile-time: greedy decoding never reads kv_div (one more scalar-load round trip)
         seq = bh / H;
-        bh_kv = (long)(seq / kv_div) * H + (bh - seq * H);
+        // GRP without IND: this launch serves query rows n_rows .. of a longer list (q, out, partial and tickets
+        // are local to the launch; kc / vc are not)
+        const int seq_all = (GRP && !IND) ? seq + n_rows : seq;
+        bh_kv = (long)(seq_all / kv_div) * H + (bh - seq * H);
     }
     const f16* kb = kc + (bh_kv * tstride + t0) * 64 + dc * 8;
     const f16* vb = vc + (bh_kv * tstride + t0) * 64 + dc * 8;
@@ -890,6 +893,92 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
         }
 }
 
+// ------------------------------------------------------------------ prompt prefill
+// The forced prompt (start-of-previous + initial prompt + task tokens: several dozen ids with the
+// reference's initial_prompt, transcribe.py:40,111) is known before decoding starts, so all of its
+// positions go through the decoder in ONE pass of M = batch * P rows (row m = sequence m / P,
+// position m % P) on the big GEMM kernels, instead of P latency-bound single-position steps.  These
+// are the pieces of that pass that are not GEMMs or the (re-used) cross-attention kernel.
+
+// x[m][:] = token embedding of forced[m / P][m % P] + learned position m % P (modeling_whisper.py:737-762)
+__global__ __launch_bounds__(256) void prefill_embed_kernel(const int* __restrict__ forced, int n_forced, int P,
+                                                            const f16* __restrict__ tok_emb, const f16* __restrict__ pos_emb,
+                                                            float* __restrict__ x, int D) {
+    const int m = blockIdx.x, b = m / P, j = m - b * P;
+    const int tok = forced[(long)b * n_forced + j];
+    for (int c = threadIdx.x; c < D; c += 256) x[(long)m * D + c] = (float)tok_emb[(long)tok * D + c] + (float)pos_emb[(long)j * D + c];
+}
+
+// Causal self-attention among the P prompt positions of one (sequence, head), one wave per query.
+// qkv: [M][3D] fp16 rows of (scaled q | k | v); every wave also files its own position's k and v rows
+// in the layer's cache ([B][H][Tctx][64]), where the sampled positions will find them.
+// Scores: lane l owns keys l, l+64, ... (<= 7 of them: P <= 448); output: lane l owns dimension l.
+__global__ __launch_bounds__(256) void prefill_self_attn_kernel(const f16* __restrict__ qkv, f16* __restrict__ kcache,
+                                                                f16* __restrict__ vcache, f16* __restrict__ out, int H, int P,
+                                                                int Tctx, int D) {
+    constexpr int KPL = 7;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);      // query position
+    if (j >= P) return;                                      // whole wave
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const long ld = 3L * D;
+    const f16* base = qkv + (long)b * P * ld + h * 64;      // row j' of this sequence: base + j' * ld
+    const f16* qr = base + (long)j * ld;
+    {   // cache rows of position j
+        const long dst = (((long)b * H + h) * Tctx + j) * 64 + lane;
+        kcache[dst] = qr[D + lane];
+        vcache[dst] = qr[2 * D + lane];
+    }
+    float q[64];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const half8 v = *reinterpret_cast<const half8*>(qr + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)v[e];
+    }
+    float sc[KPL];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const int key = lane + 64 * i;
+        sc[i] = -3.0e38f;
+        if (key <= j) {
+            const f16* kr = base + (long)key * ld + D;
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const half8 v = *reinterpret_cast<const half8*>(kr + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += q[c * 8 + e] * (float)v[e];
+            }
+            sc[i] = d;
+        }
+        mx = fmaxf(mx, sc[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) { sc[i] = (lane + 64 * i <= j) ? __expf(sc[i] - mx) : 0.f; sum += sc[i]; }
+    sum = wave_sum(sum);
+    float o = 0.f;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        if (64 * i > j) break;                               // wave-uniform
+        const int nk = min(64, j + 1 - 64 * i);
+        for (int k = 0; k < nk; ++k) o += __shfl(sc[i], k) * (float)base[(long)(64 * i + k) * ld + 2 * D + lane];
+    }
+    out[((long)b * P + j) * D + h * 64 + lane] = (f16)(o / sum);
+}
+
+// dx[b][:] = x[b * P + P - 1][:] (the residual row of the last prompt position) and position = P - 1:
+// the state a step-by-step run would be in just before the final LayerNorm of its P-th step.
+__global__ __launch_bounds__(256) void prefill_last_rows_kernel(const float* __restrict__ x, float* __restrict__ dx, int P, int D,
+                                                                DecState* __restrict__ st) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < D; c += 256) dx[(long)b * D + c] = x[((long)b * P + P - 1) * D + c];
+    if (b == 0 && threadIdx.x == 0) st->pos = P - 1;
+}
+
 template <int MT, int KPW, int XV, int R, bool W8>
 void launch_gemv_r(const GemvParams& p, int nw, hipStream_t s) {
     size_t lds = (size_t)nw * R * MT * 64 * 16;
@@ -1078,14 +1167,27 @@ void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, 
 }
 
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
-                           int* tickets, hipStream_t s, int kv_div) {
+                           int* tickets, hipStream_t s, int kv_div, int row0) {
     // 4 key ranges of 375 frames per (sequence, head); 256 threads = 32 row groups x 12 rows = 384 >= 375
     if (kv_div > 1)
         hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, kc, vc,
-                           out, H, T, T, (const DecState*)nullptr, partial, tickets, kv_div, (const int*)nullptr, B);
+                           out, H, T, T, (const DecState*)nullptr, partial, tickets, kv_div, (const int*)nullptr, row0);
     else
         hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, kc, vc, out, H,
                            T, T, (const DecState*)nullptr, partial, tickets, 1, (const int*)nullptr, B);
+}
+
+void launch_prefill_embed(const int* forced, int n_forced, int B, int P, const f16* tok_emb, const f16* pos_emb, float* x, int D,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(prefill_embed_kernel, dim3(B * P), dim3(256), 0, s, forced, n_forced, P, tok_emb, pos_emb, x, D);
+}
+
+void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out, int B, int H, int P, int Tctx, int D, hipStream_t s) {
+    hipLaunchKernelGGL(prefill_self_attn_kernel, dim3(B * H, (P + 3) / 4), dim3(256), 0, s, qkv, kcache, vcache, out, H, P, Tctx, D);
+}
+
+void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s) {
+    hipLaunchKernelGGL(prefill_last_rows_kernel, dim3(B), dim3(256), 0, s, x, dx, P, D, st);
 }
 
 void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s) {

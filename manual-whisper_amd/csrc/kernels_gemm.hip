@@ -156,8 +156,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
         }
         return;
     }
-    if (p.w_scale) {            // fp16 product over fp8 weight codes expanded to fp16: the residual projections
-        gemm_epilogue_t<MI, OUT_RESID_F32, false, 1>(p, acc, m0, n0, wm, wn, fr, fg);
+    if (p.w_scale) {            // fp16 product over fp8 weight codes expanded to fp16: residual projections, prompt prefill
+        if (p.out_mode == OUT_RESID_F32) gemm_epilogue_t<MI, OUT_RESID_F32, false, 1>(p, acc, m0, n0, wm, wn, fr, fg);
+        else if (p.gelu) gemm_epilogue_t<MI, OUT_F16, true, 1>(p, acc, m0, n0, wm, wn, fr, fg);
+        else gemm_epilogue_t<MI, OUT_F16, false, 1>(p, acc, m0, n0, wm, wn, fr, fg);
         return;
     }
     switch (p.out_mode) {

@@ -53,7 +53,7 @@ struct GemmParams {
     // f8 != 0: A and W hold OCP e4m3 bytes (lda, ldw, K still count elements; K % 128 == 0) and the
     // product is scaled by a_scale[m] * w_scale[n] before the bias.  Output modes: OUT_F16 with GELU,
     // OUT_QKV_SPLIT, OUT_KV_SPLIT.  f8 == 0 with w_scale != null: fp16 operands, columns scaled by
-    // w_scale[n] before the bias (W holds unscaled fp8 codes expanded to fp16); OUT_RESID_F32 without GELU only.
+    // w_scale[n] before the bias (W holds unscaled fp8 codes expanded to fp16); OUT_RESID_F32 without GELU, or OUT_F16.
     int f8; const float* a_scale; const float* w_scale;
 };
 void launch_gemm(const GemmParams& p, hipStream_t s);
@@ -134,9 +134,11 @@ constexpr int kSelfAttnBuckets = 4;
 // B*H*kXattnSplit*68 floats and `tickets` B*H ints that must be zero before the first launch
 // (every launch leaves them zero again).
 constexpr int kXattnSplit = 4;
-// kv_div > 1: sequence r attends over the encoder cache of recording r / kv_div (the beams of one recording)
+// kv_div > 1: query row r attends over the encoder cache of recording (row0 + r) / kv_div (the beams of one
+// recording; the prompt positions of one sequence).  row0: index of this launch's first row in the whole list.
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
-                           int* tickets, hipStream_t s, int kv_div = 1);
+                           int* tickets, hipStream_t s, int kv_div = 1, int row0 = 0);
+constexpr int kPrefillSlabRows = 256;      // query rows per cross-attention launch of the prompt prefill
 
 struct FinalizeParams {
     DecState* st;
@@ -150,6 +152,15 @@ struct FinalizeParams {
     int* finished;              // [B]
 };
 void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s);
+
+// ---------------------------------------------------------------- prompt prefill (all forced positions in one pass)
+// rows m = sequence * P + position.  forced: int [B][n_forced] (the first P of each row are used)
+void launch_prefill_embed(const int* forced, int n_forced, int B, int P, const f16* tok_emb, const f16* pos_emb, float* x, int D,
+                          hipStream_t s);
+// qkv [B*P][3D] fp16 (scaled q | k | v) -> k, v rows into the layer's cache [B][H][Tctx][64] and causal attention out [B*P][D]; P <= 448
+void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out, int B, int H, int P, int Tctx, int D, hipStream_t s);
+// dx [B][D] = x rows of the last position; st->pos = P - 1
+void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s);
 
 // ---------------------------------------------------------------- beam search bookkeeping
 constexpr int kMaxBeam = 8;

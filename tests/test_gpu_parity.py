@@ -342,3 +342,49 @@ def test_batches_above_16_use_the_two_tile_kernels(name):
         assert np.abs(got - orc.forced_logits(orc.encode(mel_ref), toks[: len(sel)])).max() < LOGIT_ATOL
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# prompt prefill: all forced positions in one pass (the reference's initial_prompt makes the prompt long)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("weight_format", ["f16", "fp8"])
+@pytest.mark.parametrize("name,n_prompt,B", [("micro", 37, 5), ("tiny", 70, 3), ("micro", 2, 16), ("micro", 223, 2)])
+def test_prompt_prefill_matches_stepping_and_oracle(name, n_prompt, B, weight_format):
+    """A long forced prompt (as `<|startofprev|> initial prompt ... <|notimestamps|>` is): the one-pass prefill gives
+    the logits and ids of stepping through the prompt position by position, and both agree with the oracle.
+    Lengths: 2 (shortest prefilled), 37 / 70 (the reference's prompt is about this long), 223 (the longest prompt
+    Whisper allows: half the text context minus one)."""
+    from manual_whisper_amd.engine import Engine
+    dims = mw.get_dims(name)
+    w = synth.make_weights_np(dims, 1234)
+    eng = Engine(dims, 0, 16, weight_format=weight_format)
+    eng.load_weights(w)
+    try:
+        rng = np.random.default_rng(n_prompt)
+        base = synthetic_options(dims, max_new=8)
+        prompt = tuple(int(t) for t in rng.integers(0, dims.vocab, size=n_prompt - 1)) + (base.prompt[-1],)
+        opts = DecodeOptions(prompt, base.eot, base.suppress, base.begin_suppress, 8)
+        eng.set_decode_options(opts)
+        pcm = synth.make_pcm_np(B, 55)
+        eng.logmel(pcm, want_output=False)
+        enc = eng.encode(B)
+        eng.set_option("prefill", 0)
+        ids0, lens0, log0 = eng.decode_greedy(B, want_logits=True)
+        eng.set_option("prefill", 1)
+        ids1, lens1, log1 = eng.decode_greedy(B, want_logits=True)
+        orc = WhisperOracle(dims, w, weight_format=weight_format)
+        wi, wl, wlog = orc.greedy(enc, list(prompt), 8, opts.eot, opts.effective_suppress(), opts.begin_suppress, return_logits=True)
+        n = wlog.shape[0]
+        assert np.abs(log1[0] - wlog[0]).max() < LOGIT_ATOL            # first sampled position: straight out of the prefill
+        assert np.abs(log0[0] - wlog[0]).max() < LOGIT_ATOL
+        assert_ids_match_up_to_ties(ids1, wi, orc.last_margins)
+        assert_ids_match_up_to_ties(ids0, wi, orc.last_margins)
+        same = (ids1 == wi).all(axis=1) & (ids0 == wi).all(axis=1)      # sequences on the oracle's path: later logits comparable too
+        if same.any():
+            assert np.abs(log1[:n, same] - wlog[:, same]).max() < LOGIT_ATOL
+            assert np.abs(log1[:n, same] - log0[:n, same]).max() < LOGIT_ATOL
+        # the whole-path call and a forked engine take the same route
+        ids2, _ = eng.transcribe_batch(pcm)
+        assert (ids2 == ids1).all()
+    finally:
+        eng.close()
