@@ -168,8 +168,8 @@ int mw_profile_cross_attention(mw_ctx* ctx, int batch, int iters, float* mean_ms
 
 /* Engine options: key "graph" (1 = capture the decode step into a hipGraph, default 1),
  * "check_every" (decode steps between host checks for all-finished, default 16),
- * "prefill" (1 = greedy decoding sends all forced prompt positions through the decoder in one pass
- * instead of one step per position, default 1; the reference's initial_prompt, transcribe.py:40,111,
+ * "prefill" (1 = greedy decoding and beam search send all forced prompt positions through the decoder
+ * in one pass instead of one step per position, default 1; the reference's initial_prompt, transcribe.py:40,111,
  * makes the prompt several dozen ids long). */
 int mw_set_option(mw_ctx* ctx, const char* key, int value);
 

@@ -805,7 +805,9 @@ static FinalizeParams finalize_params(mw_ctx* ctx, int n_forced) {
 // Borrows the encoder's workspaces (idle while decoding): x, xn, q (as the [M][3D] q|k|v rows), k (as the
 // cross-attention queries), att, hid.  Same arithmetic as the steps (fp16 operands, fp32 accumulation, fp8
 // weight codes expanded to fp16 with the row scale in the epilogue), on the GEMM kernels instead of the GEMVs.
-static int run_prefill(mw_ctx* ctx, int B, int P) {
+// Beam search (beam > 1): B recordings, each prompt once; the k/v rows go to the cache rows of the recording's
+// first beam, `src_rows` points every beam at them, and dx gets `beam` copies of each last row.
+static int run_prefill(mw_ctx* ctx, int B, int P, int beam = 1, int* src_rows = nullptr) {
     const mw_model_desc& d = ctx->d;
     const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, Tc = d.n_text_ctx;
     const int M = B * P;
@@ -820,12 +822,12 @@ static int run_prefill(mw_ctx* ctx, int B, int P) {
         if (ctx->fp8) { launch_fp8_to_f16(w.w8, ctx->wexp, (long)N * K, s); p.W = ctx->wexp; p.w_scale = w.ws; }
         return p;
     };
-    launch_prefill_embed(ctx->forced, P, B, P, ctx->tok_emb, ctx->dec_pos, ctx->x, D, s);
+    launch_prefill_embed(ctx->forced, P * beam, B, P, ctx->tok_emb, ctx->dec_pos, ctx->x, D, s);     // forced: [B*beam][P], equal within a recording
     for (int li = 0; li < d.dec_layers; ++li) {
         const DecLayerW& l = ctx->dec[li];
         launch_layernorm(ctx->x, l.ln1.g, l.ln1.b, ctx->xn, nullptr, M, D, s);
         {   GemmParams p = gemm(ctx->xn, D, l.qkv, 3 * D); p.scale = qscale; p.scale_ncols = D; p.C = qkv; p.ldc = 3 * D; launch_gemm(p, s); }
-        launch_prefill_self_attn(qkv, ctx->selfK + li * self_layer, ctx->selfV + li * self_layer, ctx->att, B, H, P, Tc, D, s);
+        launch_prefill_self_attn(qkv, ctx->selfK + li * self_layer, ctx->selfV + li * self_layer, ctx->att, B, H, P, Tc, D, s, beam);
         {   GemmParams p = gemm(ctx->att, D, l.out, D); p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D; launch_gemm(p, s); }
         launch_layernorm(ctx->x, l.ln2.g, l.ln2.b, ctx->xn, nullptr, M, D, s);
         {   GemmParams p = gemm(ctx->xn, D, l.cq, D); p.scale = qscale; p.scale_ncols = D; p.C = cq; p.ldc = D; launch_gemm(p, s); }
@@ -839,7 +841,7 @@ static int run_prefill(mw_ctx* ctx, int B, int P) {
         {   GemmParams p = gemm(ctx->xn, D, l.fc1, F); p.gelu = 1; p.C = ctx->hid; p.ldc = F; launch_gemm(p, s); }
         {   GemmParams p = gemm(ctx->hid, F, l.fc2, D); p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D; launch_gemm(p, s); }
     }
-    launch_prefill_last_rows(ctx->x, ctx->dx, B, P, D, ctx->st, s);
+    launch_prefill_last_rows(ctx->x, ctx->dx, B, P, D, ctx->st, s, beam, src_rows);
     HIPCHK(hipGetLastError());
     return MW_OK;
 }
@@ -981,8 +983,15 @@ extern "C" int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience
     FinalizeParams fp = finalize_params(ctx, P);
     const int n_steps = P + max_new - 1;
     const bool graph = ctx->use_graph != 0;
-    int host_fin = 0, steps_run = 0;
-    for (int step = 0; step < n_steps; ++step) {
+    int host_fin = 0, steps_run = 0, first_step = 0;
+    if (ctx->use_prefill && P >= 2) {                       // the prompt once per recording, in one pass
+        int r = run_prefill(ctx, n_audio, P, beam, bp.src_rows);
+        if (r) return r;
+        enqueue_step_tail(ctx, R, true, fp, &bp);
+        HIPCHK(hipGetLastError());
+        first_step = steps_run = P;
+    }
+    for (int step = first_step; step < n_steps; ++step) {
         if (graph) {
             hipGraphExec_t g;
             int r = ensure_graph(ctx, R, true, fp, (beam << 24) + (max_cand << 16) + R * 1024 + P, step + 1, &g, &bp);

@@ -913,9 +913,11 @@ __global__ __launch_bounds__(256) void prefill_embed_kernel(const int* __restric
 // qkv: [M][3D] fp16 rows of (scaled q | k | v); every wave also files its own position's k and v rows
 // in the layer's cache ([B][H][Tctx][64]), where the sampled positions will find them.
 // Scores: lane l owns keys l, l+64, ... (<= 7 of them: P <= 448); output: lane l owns dimension l.
+// cache_seq_stride: sequence b files its rows under cache sequence b * cache_seq_stride (beam search: the
+// prompt rows of a recording live once, in the cache rows of its first beam).
 __global__ __launch_bounds__(256) void prefill_self_attn_kernel(const f16* __restrict__ qkv, f16* __restrict__ kcache,
                                                                 f16* __restrict__ vcache, f16* __restrict__ out, int H, int P,
-                                                                int Tctx, int D) {
+                                                                int Tctx, int D, int cache_seq_stride) {
     constexpr int KPL = 7;
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.y * 4 + (threadIdx.x >> 6);      // query position
@@ -925,7 +927,7 @@ __global__ __launch_bounds__(256) void prefill_self_attn_kernel(const f16* __res
     const f16* base = qkv + (long)b * P * ld + h * 64;      // row j' of this sequence: base + j' * ld
     const f16* qr = base + (long)j * ld;
     {   // cache rows of position j
-        const long dst = (((long)b * H + h) * Tctx + j) * 64 + lane;
+        const long dst = (((long)b * cache_seq_stride * H + h) * Tctx + j) * 64 + lane;
         kcache[dst] = qr[D + lane];
         vcache[dst] = qr[2 * D + lane];
     }
@@ -972,10 +974,15 @@ __global__ __launch_bounds__(256) void prefill_self_attn_kernel(const f16* __res
 
 // dx[b][:] = x[b * P + P - 1][:] (the residual row of the last prompt position) and position = P - 1:
 // the state a step-by-step run would be in just before the final LayerNorm of its P-th step.
+// rep > 1 (beam search): every beam of recording b gets the row, and src_rows [Tctx][n_seq * rep] of the
+// prompt positions point all beams at the cache rows of the recording's first beam.
 __global__ __launch_bounds__(256) void prefill_last_rows_kernel(const float* __restrict__ x, float* __restrict__ dx, int P, int D,
-                                                                DecState* __restrict__ st) {
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < D; c += 256) dx[(long)b * D + c] = x[((long)b * P + P - 1) * D + c];
+                                                                DecState* __restrict__ st, int rep, int* __restrict__ src_rows) {
+    const int b = blockIdx.x, R = gridDim.x * rep;
+    for (int j = 0; j < rep; ++j)
+        for (int c = threadIdx.x; c < D; c += 256) dx[((long)b * rep + j) * D + c] = x[((long)b * P + P - 1) * D + c];
+    if (src_rows)
+        for (int i = threadIdx.x; i < P * rep; i += 256) src_rows[(long)(i / rep) * R + b * rep + (i % rep)] = b * rep;
     if (b == 0 && threadIdx.x == 0) st->pos = P - 1;
 }
 
@@ -1182,12 +1189,14 @@ void launch_prefill_embed(const int* forced, int n_forced, int B, int P, const f
     hipLaunchKernelGGL(prefill_embed_kernel, dim3(B * P), dim3(256), 0, s, forced, n_forced, P, tok_emb, pos_emb, x, D);
 }
 
-void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out, int B, int H, int P, int Tctx, int D, hipStream_t s) {
-    hipLaunchKernelGGL(prefill_self_attn_kernel, dim3(B * H, (P + 3) / 4), dim3(256), 0, s, qkv, kcache, vcache, out, H, P, Tctx, D);
+void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out, int B, int H, int P, int Tctx, int D, hipStream_t s,
+                              int cache_seq_stride) {
+    hipLaunchKernelGGL(prefill_self_attn_kernel, dim3(B * H, (P + 3) / 4), dim3(256), 0, s, qkv, kcache, vcache, out, H, P, Tctx, D,
+                       cache_seq_stride);
 }
 
-void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s) {
-    hipLaunchKernelGGL(prefill_last_rows_kernel, dim3(B), dim3(256), 0, s, x, dx, P, D, st);
+void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s, int rep, int* src_rows) {
+    hipLaunchKernelGGL(prefill_last_rows_kernel, dim3(B), dim3(256), 0, s, x, dx, P, D, st, rep, src_rows);
 }
 
 void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s) {

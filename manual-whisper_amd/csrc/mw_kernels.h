@@ -158,9 +158,13 @@ void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new
 void launch_prefill_embed(const int* forced, int n_forced, int B, int P, const f16* tok_emb, const f16* pos_emb, float* x, int D,
                           hipStream_t s);
 // qkv [B*P][3D] fp16 (scaled q | k | v) -> k, v rows into the layer's cache [B][H][Tctx][64] and causal attention out [B*P][D]; P <= 448
-void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out, int B, int H, int P, int Tctx, int D, hipStream_t s);
-// dx [B][D] = x rows of the last position; st->pos = P - 1
-void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s);
+// cache_seq_stride: sequence b files its rows under cache sequence b * cache_seq_stride
+void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out, int B, int H, int P, int Tctx, int D, hipStream_t s,
+                              int cache_seq_stride = 1);
+// dx [B*rep][D] = x rows of the last position, `rep` copies each; st->pos = P - 1; src_rows (beam search, else null):
+// int [Tctx][B*rep], its first P rows are pointed at the cache rows b * rep
+void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s, int rep = 1,
+                              int* src_rows = nullptr);
 
 // ---------------------------------------------------------------- beam search bookkeeping
 constexpr int kMaxBeam = 8;

@@ -176,3 +176,40 @@ def test_model_transcribe_with_beam_size():
             assert res["segments"][a]["tokens"] == [int(t) for t in ids[0, : lens[0]]]
     finally:
         model.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n_prompt", [("micro", 41), ("tiny", 70)])
+def test_beam_search_with_a_long_prompt_prefilled(name, n_prompt):
+    """whisperx's default decoding with the reference's initial_prompt: a beam of 5 behind a prompt of several
+    dozen ids.  The prompt goes through the decoder once per recording (its k/v rows shared by the beams through
+    the cache-row table); results must be the oracle's, and those of stepping through the prompt."""
+    from manual_whisper_amd.engine import Engine
+    dims = mw.get_dims(name)
+    w = synth.make_weights_np(dims, 1234)
+    orc = WhisperOracle(dims, w)
+    pcm = synth.make_pcm_np(3, seed=2)
+    mel = log_mel(pcm, dims.n_mels)
+    enc = orc.encode(mel)
+    eng = Engine(dims, 0, 16)
+    try:
+        eng.load_weights(w)
+        base = synthetic_options(dims, max_new=8)
+        rng = np.random.default_rng(n_prompt)
+        prompt = tuple(int(t) for t in rng.integers(0, dims.vocab, size=n_prompt - 1)) + (base.prompt[-1],)
+        o = DecodeOptions(prompt, base.eot, base.suppress, base.begin_suppress, 8)
+        eng.set_decode_options(o)
+        eng.encode(3, mel=mel, want_output=False)
+        want = orc.beam_search(enc, list(prompt), 8, o.eot, 5, 1.0, o.suppress, o.begin_suppress)
+        runs = {}
+        for prefill in (0, 1):
+            eng.set_option("prefill", prefill)
+            got = eng.decode_beam(3, 5, 1.0, want_hypotheses=True)
+            _compare(got, want, orc.last_beam_margins, orc, enc, o, 8)
+            runs[prefill] = got
+        for a in range(3):
+            if orc.last_beam_margins[a] > 2 * SCORE_ATOL:
+                assert (runs[0][0][a] == runs[1][0][a]).all() or abs(float(runs[0][2][a]) - float(runs[1][2][a])) < SCORE_ATOL / 4
+        assert eng.stage_ms()["decode_steps"] == n_prompt + 8 - 1          # positions processed, prefilled ones included
+    finally:
+        eng.close()
