@@ -73,6 +73,8 @@ def stage_rooflines(dims, batch, n_prompt, n_new, ms, layer_weight_bytes=2):
     floor_ms = (mel_bytes + dec_bytes) / (HBM_PEAK_GBS * 1e6) + (enc_flop + ckv_flop) / (MFMA_F16_PEAK_TFLOPS * 1e9)
     out["sum_of_stage_floors_ms"] = round(floor_ms, 2)
     out["solo_step_ms"] = round(sum(ms[k] for k in ("logmel", "encoder", "cross_kv", "decode")), 2)
+    out["algorithmic_hbm_bytes_per_step"] = mel_bytes + dec_bytes
+    out["algorithmic_flop_per_step"] = enc_flop + ckv_flop
     return out
 
 
@@ -214,12 +216,20 @@ def main():
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items() if k != "decode_steps"},
             "decode_steps_per_step": int(stage.get("decode_steps", 0)),
             "stage_roofline": stage_rooflines(dims, batch, len(opts.prompt), NEW_TOKENS, solo_ms, 1 if args.weights == "fp8" else 2),
+            "whole_run": None,
             "roofline": {"kernel": "dec_attn_kernel<256,12,4> (decode cross-attention, one launch per layer per token)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": XATTN_TRAFFIC_BYTES if batch == 16 else None,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/round1_hbm_counters.csv",
                          "bytes_per_launch": ca_bytes, "avg_launch_us": round(ca_ms * 1e3, 2)},
         }
+        # the timed region as a whole (engines overlapped): algorithmic HBM bytes and MFMA flops of all steps over the wall time
+        sr = out["stage_roofline"]
+        hb = sr["algorithmic_hbm_bytes_per_step"] * world * args.steps / elapsed / 1e9
+        fl = sr["algorithmic_flop_per_step"] * world * args.steps / elapsed / 1e12
+        out["whole_run"] = {"hbm_GBps_per_gpu": round(hb / world, 1), "hbm_frac": round(hb / world / HBM_PEAK_GBS, 4),
+                            "mfma_TFLOPs_per_gpu": round(fl / world, 1), "mfma_frac": round(fl / world / MFMA_F16_PEAK_TFLOPS, 4),
+                            "step_floor_over_step": round(sr["sum_of_stage_floors_ms"] / (elapsed / args.steps * 1e3), 4)}
         if weights_np is not None:
             def gpu_ids(pcm, n_new):
                 o = synthetic_options(dims, max_new=n_new, suppress_eot=True)

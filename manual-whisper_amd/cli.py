@@ -7,6 +7,7 @@ Environment (reference transcribe.py:30-36 plus this engine's own knobs):
   WHISPER_MODEL  model size / local checkpoint directory / synthetic:<size> (default large-v3)
   MW_MODEL_DIR   where model-size names are looked up
   MW_ENGINES     engines in flight on the GPU (default 2)
+  MW_DTYPE       float16 (default) or float8 (e4m3 Linear weights quantised at load)
   HF_TOKEN       accepted for compatibility; diarization is not part of this engine
 Launched under torch.distributed.run, the chunks are sharded over the ranks and rank 0 writes the files.
 """
