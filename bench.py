@@ -45,7 +45,7 @@ NEW_TOKENS = 128
 MODEL = "large-v3"
 
 
-def stage_rooflines(dims, batch, n_prompt, n_new, ms, layer_weight_bytes=2):
+def stage_rooflines(dims, batch, n_prompt, n_new, ms, layer_weight_bytes=2, kv8=False):
     """Algorithmic bytes / flops of each stage of one step over the stage's measured time (one
     engine alone on the GPU).  2*M*N*K per contraction, softmax/LayerNorm/GELU not counted."""
     D, F, T = dims.d_model, dims.ffn_dim, dims.n_audio_ctx
@@ -55,7 +55,7 @@ def stage_rooflines(dims, batch, n_prompt, n_new, ms, layer_weight_bytes=2):
     ckv_flop = batch * 2 * T * D * 2 * D * dims.dec_layers
     steps = n_prompt + n_new - 1
     w_bytes = dims.dec_layers * (6 * D * D + 2 * D * F) * layer_weight_bytes + dims.vocab * D * 2
-    ckv_bytes = batch * dims.dec_layers * 2 * T * D * 2
+    ckv_bytes = batch * dims.dec_layers * 2 * T * (D + 4 * dims.n_heads if kv8 else D * 2)
     self_bytes = sum(batch * dims.dec_layers * 2 * (t + 1) * D * 2 for t in range(steps))
     dec_bytes = steps * (w_bytes + ckv_bytes) + self_bytes
 
@@ -78,14 +78,14 @@ def stage_rooflines(dims, batch, n_prompt, n_new, ms, layer_weight_bytes=2):
     return out
 
 
-def cpu_baseline(dims, weights_np, opts, gpu_ids_fn, weight_format="f16"):
+def cpu_baseline(dims, weights_np, opts, gpu_ids_fn, weight_format="f16", kv_format="f16"):
     """Oracle on the host: one 30 s chunk, 8 sampled tokens; decode time extrapolated to 128."""
     from threadpoolctl import threadpool_info
     from manual_whisper_amd import synth
     from oracle.whisper_ref import WhisperOracle, log_mel          # checker / baseline leg only
     sample_new = 8
     pcm = synth.make_pcm_np(1, seed=100)
-    orc = WhisperOracle(dims, weights_np, weight_format)
+    orc = WhisperOracle(dims, weights_np, weight_format, kv_format)
     t0 = time.perf_counter()
     mel = log_mel(pcm, dims.n_mels)
     t1 = time.perf_counter()
@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--weights", choices=("f16", "fp8"), default="f16",
                     help="fp8: BASELINE configs[4] (e4m3 Linear weights, fp8 MFMA in the encoder); the default is the metric's configs[2]")
+    ap.add_argument("--kv", choices=("f16", "fp8"), default="f16", help="fp8: e4m3 cross-attention K/V cache (needs --weights fp8)")
     ap.add_argument("--batch", type=int, default=16, help="30 s chunks per step per GPU (configs[4] uses 32)")
     args = ap.parse_args()
 
@@ -150,7 +151,7 @@ def main():
     opts = synthetic_options(dims, max_new=NEW_TOKENS, suppress_eot=True)
     weights = synth.make_weights_torch(dims, seed=1234, device=dev)
     batch = args.batch
-    eng = Engine(dims, device=local_rank, max_batch=batch, weight_format=args.weights)
+    eng = Engine(dims, device=local_rank, max_batch=batch, weight_format=args.weights, kv_format=args.kv)
     eng.load_weights(weights)
     eng.set_decode_options(opts)
     pool = EnginePool(eng, args.engines)
@@ -209,17 +210,18 @@ def main():
             "dtype": "f16" if args.weights == "f16" else "fp8 weights (e4m3) / f16 activations, fp8 MFMA for the encoder's LayerNorm-fed products",
             "data": "synthetic",
             "rtf": round(elapsed / audio_s, 6),
-            "config": {"workload": f"whisper-{args.model} {'fp16' if args.weights == 'f16' else 'fp8 weights'}, batch={batch}x30 s chunks per GPU, greedy, "
+            "config": {"workload": f"whisper-{args.model} {'fp16' if args.weights == 'f16' else 'fp8 weights'}{' + fp8 cross K/V cache' if args.kv == 'fp8' else ''}, batch={batch}x30 s chunks per GPU, greedy, "
                                    f"{len(opts.prompt)} prompt + {NEW_TOKENS} sampled tokens per chunk (EOT suppressed), "
                                    f"hipGraph decode step, {args.engines} engines (steps) in flight per GPU",
                        "parallelism": f"dp{world} over chunks, one all_gather of ids at the end"},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items() if k != "decode_steps"},
             "decode_steps_per_step": int(stage.get("decode_steps", 0)),
-            "stage_roofline": stage_rooflines(dims, batch, len(opts.prompt), NEW_TOKENS, solo_ms, 1 if args.weights == "fp8" else 2),
+            "stage_roofline": stage_rooflines(dims, batch, len(opts.prompt), NEW_TOKENS, solo_ms, 1 if args.weights == "fp8" else 2, args.kv == "fp8"),
             "whole_run": None,
-            "roofline": {"kernel": "dec_attn_kernel<256,12,4> (decode cross-attention, one launch per layer per token)",
+            "roofline": {"kernel": ("dec_attn_kernel<256,12,4>" if args.kv == "f16" else "cross_attn8_kernel<256,12,4>")
+                                   + " (decode cross-attention, one launch per layer per token)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": XATTN_TRAFFIC_BYTES if batch == 16 else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": XATTN_TRAFFIC_BYTES if batch == 16 and args.kv == "f16" else None,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/round1_hbm_counters.csv",
                          "bytes_per_launch": ca_bytes, "avg_launch_us": round(ca_ms * 1e3, 2)},
         }
@@ -236,7 +238,7 @@ def main():
                 eng.set_decode_options(o)
                 ids, _ = eng.transcribe_batch(pcm)
                 return ids
-            out["cpu_baseline"] = cpu_baseline(dims, weights_np, opts, gpu_ids, args.weights)
+            out["cpu_baseline"] = cpu_baseline(dims, weights_np, opts, gpu_ids, args.weights, args.kv)
         print(json.dumps(out), flush=True)
     pool.close()
     if world > 1:

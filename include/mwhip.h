@@ -52,6 +52,14 @@ typedef enum { MW_F32 = 0, MW_F16 = 1, MW_BF16 = 2 } mw_dtype;
  *    embeddings, LayerNorm parameters and biases stay fp16/fp32. */
 typedef enum { MW_WEIGHTS_F16 = 0, MW_WEIGHTS_FP8 = 1 } mw_weight_format;
 
+/* How the per-layer cross-attention K/V of the encoder output is cached for the decoder (the largest stream of
+ * a decode step: 245.8 MB per sequence per step at large-v3 in fp16).  No counterpart in the reference.
+ *  MW_KV_F16: fp16.
+ *  MW_KV_FP8: OCP e4m3 codes with one fp32 scale per (sequence, head, frame) row of 64 values (scale =
+ *    max|.| / 448, round to nearest even), written by the projection's epilogue; 130.6 MB per sequence per
+ *    step.  Only together with MW_WEIGHTS_FP8. */
+typedef enum { MW_KV_F16 = 0, MW_KV_FP8 = 1 } mw_kv_format;
+
 /* Architecture of the checkpoint (what `MODEL_SIZE`, reference transcribe.py:33,
  * resolves to inside whisperx.load_model). head_dim must be 64. */
 typedef struct {
@@ -65,6 +73,7 @@ typedef struct {
     int32_t n_audio_ctx;   /* 1500 */
     int32_t n_text_ctx;    /* 448  */
     int32_t weight_format; /* mw_weight_format; fp8 needs d_model and ffn_dim to be multiples of 128 */
+    int32_t kv_format;     /* mw_kv_format */
 } mw_model_desc;
 
 /* Decoding rules; the asr_options / language arguments of whisperx.load_model

@@ -21,10 +21,11 @@ SYMBOLS = (
 
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_mels", "d_model", "n_heads", "enc_layers", "dec_layers",
-                                          "ffn_dim", "vocab", "n_audio_ctx", "n_text_ctx", "weight_format")]
+                                          "ffn_dim", "vocab", "n_audio_ctx", "n_text_ctx", "weight_format", "kv_format")]
 
 
 WEIGHT_FORMATS = {"f16": 0, "fp8": 1}        # mw_weight_format
+KV_FORMATS = {"f16": 0, "fp8": 1}            # mw_kv_format
 
 
 class DecodeOpts(C.Structure):

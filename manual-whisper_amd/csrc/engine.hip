@@ -67,6 +67,9 @@ struct mw_ctx {
     f16 *q = nullptr, *k = nullptr, *vT = nullptr, *att = nullptr, *hid = nullptr, *enc_out = nullptr;
     float* enc_out32 = nullptr;
     f16 *crossK = nullptr, *crossV = nullptr;             // [L][B][H][1500][64]
+    uint8_t *crossK8 = nullptr, *crossV8 = nullptr;       // MW_KV_FP8: e4m3 codes in the same layout ...
+    float *crossKs = nullptr, *crossVs = nullptr;         // ... and one scale per row: [L][B][H][1500]
+    bool kv8 = false;
     int Tpad = 0;
     int mel_batch = 0, enc_batch = 0;
 
@@ -248,8 +251,13 @@ static int alloc_work(mw_ctx* ctx) {
     ALLOC(ctx->vT, B * H * 64 * (size_t)ctx->Tpad, true);
     ALLOC(ctx->att, M * D); ALLOC(ctx->hid, M * F);
     ALLOC(ctx->enc_out, M * D); ALLOC(ctx->enc_out32, M * D);
-    ALLOC(ctx->crossK, (size_t)d.dec_layers * M * D);
-    ALLOC(ctx->crossV, (size_t)d.dec_layers * M * D);
+    if (ctx->kv8) {
+        ALLOC(ctx->crossK8, (size_t)d.dec_layers * M * D); ALLOC(ctx->crossV8, (size_t)d.dec_layers * M * D);
+        ALLOC(ctx->crossKs, (size_t)d.dec_layers * M * H); ALLOC(ctx->crossVs, (size_t)d.dec_layers * M * H);
+    } else {
+        ALLOC(ctx->crossK, (size_t)d.dec_layers * M * D);
+        ALLOC(ctx->crossV, (size_t)d.dec_layers * M * D);
+    }
     // decoder workspaces
     ALLOC(ctx->st, 1, true);
     ALLOC(ctx->dx, B * D); ALLOC(ctx->dq, B * D); ALLOC(ctx->datt, B * D); ALLOC(ctx->dhid, B * F); ALLOC(ctx->dxn, B * D);
@@ -279,6 +287,8 @@ extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, m
     if (max_batch < 1 || max_batch > 32) { g_create_error = "mw_create: max_batch must be in 1..32"; return MW_ERR_ARG; }
     if (d.vocab < 16 || d.enc_layers < 1 || d.dec_layers < 1) { g_create_error = "mw_create: bad vocab/layer count"; return MW_ERR_ARG; }
     if (d.weight_format != MW_WEIGHTS_F16 && d.weight_format != MW_WEIGHTS_FP8) { g_create_error = "mw_create: weight_format must be MW_WEIGHTS_F16 or MW_WEIGHTS_FP8"; return MW_ERR_ARG; }
+    if (d.kv_format != MW_KV_F16 && d.kv_format != MW_KV_FP8) { g_create_error = "mw_create: kv_format must be MW_KV_F16 or MW_KV_FP8"; return MW_ERR_ARG; }
+    if (d.kv_format == MW_KV_FP8 && d.weight_format != MW_WEIGHTS_FP8) { g_create_error = "mw_create: MW_KV_FP8 needs MW_WEIGHTS_FP8"; return MW_ERR_ARG; }
     if (d.weight_format == MW_WEIGHTS_FP8 && (d.d_model % 128 || d.ffn_dim % 128)) { g_create_error = "mw_create: fp8 weights need d_model and ffn_dim to be multiples of 128"; return MW_ERR_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
@@ -288,6 +298,7 @@ extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, m
     mw_ctx* ctx = new mw_ctx();
     ctx->d = d; ctx->device = device; ctx->max_batch = max_batch;
     ctx->fp8 = d.weight_format == MW_WEIGHTS_FP8;
+    ctx->kv8 = d.kv_format == MW_KV_FP8;
     auto bail = [&](int code) { g_create_error = ctx->err; mw_destroy(ctx); return code; };
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(MW_ERR_HIP); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(MW_ERR_HIP); }
@@ -333,7 +344,7 @@ extern "C" int mw_fork(mw_ctx* parent, mw_ctx** out) {
     ctx->enc_pos = parent->enc_pos; ctx->enc = parent->enc; ctx->enc_ln = parent->enc_ln;
     ctx->tok_emb = parent->tok_emb; ctx->dec_pos = parent->dec_pos; ctx->dec = parent->dec; ctx->dec_ln = parent->dec_ln;
     ctx->ckv_w = parent->ckv_w; ctx->ckv_b = parent->ckv_b; ctx->ckv_w8 = parent->ckv_w8; ctx->ckv_ws = parent->ckv_ws;
-    ctx->fp8 = parent->fp8;
+    ctx->fp8 = parent->fp8; ctx->kv8 = parent->kv8;
     ctx->basis_cos = parent->basis_cos; ctx->basis_sin = parent->basis_sin; ctx->filt = parent->filt; ctx->n_mels_pad = parent->n_mels_pad;
     ctx->prompt = parent->prompt; ctx->eot = parent->eot; ctx->max_new = parent->max_new; ctx->opts_set = parent->opts_set;
     auto bail = [&](int code) { parent->err = "mw_fork: " + ctx->err; mw_destroy(ctx); return code; };
@@ -685,6 +696,11 @@ static int run_cross_kv(mw_ctx* ctx, int B) {
             p.f8 = 1; p.a_scale = ctx->xs; p.w_scale = ctx->ckv_ws + (size_t)li * 2 * D;
         }
         p.out_mode = OUT_KV_SPLIT; p.k = ctx->crossK + li * per_layer; p.v = ctx->crossV + li * per_layer;
+        if (ctx->kv8) {
+            const size_t per_layer_rows = (size_t)ctx->max_batch * T * H;
+            p.out_mode = OUT_KV_SPLIT8; p.k8 = ctx->crossK8 + li * per_layer; p.v8 = ctx->crossV8 + li * per_layer;
+            p.ks = ctx->crossKs + li * per_layer_rows; p.vs = ctx->crossVs + li * per_layer_rows;
+        }
         p.T = T; p.Tpad = T; p.H = H; p.D = D;
         launch_gemm(p, ctx->stream);
     }
@@ -724,6 +740,21 @@ extern "C" int mw_encode(mw_ctx* ctx, const float* mel, int batch, float* enc_ou
     return MW_OK;
 }
 
+// Cross-attention of `rows` query rows over layer li's cached encoder K/V, in whichever format the cache has.
+static void cross_attention(mw_ctx* ctx, int li, const f16* q, f16* out, int rows, int kv_div = 1, int row0 = 0) {
+    const mw_model_desc& d = ctx->d;
+    const size_t per_layer = (size_t)ctx->max_batch * d.n_audio_ctx * d.d_model;
+    if (ctx->kv8) {
+        const size_t per_layer_rows = (size_t)ctx->max_batch * d.n_audio_ctx * d.n_heads;
+        launch_dec_cross_attn8(q, ctx->crossK8 + li * per_layer, ctx->crossV8 + li * per_layer, ctx->crossKs + li * per_layer_rows,
+                               ctx->crossVs + li * per_layer_rows, out, rows, d.n_heads, d.n_audio_ctx, ctx->xpartial, ctx->xtickets,
+                               ctx->stream, kv_div, row0);
+    } else {
+        launch_dec_cross_attn(q, ctx->crossK + li * per_layer, ctx->crossV + li * per_layer, out, rows, d.n_heads, d.n_audio_ctx,
+                              ctx->xpartial, ctx->xtickets, ctx->stream, kv_div, row0);
+    }
+}
+
 // The end of a step: final LayerNorm (the same launch advances the position counter for the launches after
 // it), logits with the partial arg-max, token bookkeeping.
 static void enqueue_step_tail(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, const BeamParams* beam = nullptr) {
@@ -751,7 +782,6 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
     hipStream_t s = ctx->stream;
     const float qscale = 1.0f / sqrtf((float)kHeadDim);
     const size_t self_layer = (size_t)ctx->max_batch * D * Tc;
-    const size_t cross_layer = (size_t)ctx->max_batch * T * D;
     auto base = [&](int N, int K, const LinearW& w) {
         GemvParams p{};
         p.B = B; p.N = N; p.K = K; p.W = w.w; p.W8 = w.w8; p.w_scale = w.ws; p.bias = w.b; p.scale = 1.f; p.scale_ncols = 0; p.gelu = 0;
@@ -777,8 +807,7 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
             p.out_mode = GV_F16; p.out16 = ctx->dq;
             launch_gemv(p, s);
         }
-        launch_dec_cross_attn(ctx->dq, ctx->crossK + li * cross_layer, ctx->crossV + li * cross_layer, ctx->datt, B, H, T,
-                              ctx->xpartial, ctx->xtickets, s, beam ? beam->beam : 1);
+        cross_attention(ctx, li, ctx->dq, ctx->datt, B, beam ? beam->beam : 1);
         {   GemvParams p = base(D, D, l.co); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
         {   // LN3 + fc1 + GELU
             GemvParams p = base(F, D, l.fc1);
@@ -814,7 +843,6 @@ static int run_prefill(mw_ctx* ctx, int B, int P, int beam = 1, int* src_rows = 
     hipStream_t s = ctx->stream;
     const float qscale = 1.0f / sqrtf((float)kHeadDim);
     const size_t self_layer = (size_t)ctx->max_batch * D * Tc;
-    const size_t cross_layer = (size_t)ctx->max_batch * T * D;
     f16* qkv = ctx->q;          // [M][3D]: 3 * P <= 1500 always (P <= 448)
     f16* cq = ctx->k;           // [M][D]
     auto gemm = [&](const f16* A, int K, const LinearW& w, int N) {
@@ -833,8 +861,7 @@ static int run_prefill(mw_ctx* ctx, int B, int P, int beam = 1, int* src_rows = 
         {   GemmParams p = gemm(ctx->xn, D, l.cq, D); p.scale = qscale; p.scale_ncols = D; p.C = cq; p.ldc = D; launch_gemm(p, s); }
         for (int r0 = 0; r0 < M; r0 += kPrefillSlabRows) {
             const int rows = std::min(kPrefillSlabRows, M - r0);
-            launch_dec_cross_attn(cq + (size_t)r0 * D, ctx->crossK + li * cross_layer, ctx->crossV + li * cross_layer,
-                                  ctx->att + (size_t)r0 * D, rows, H, T, ctx->xpartial, ctx->xtickets, s, P, r0);
+            cross_attention(ctx, li, cq + (size_t)r0 * D, ctx->att + (size_t)r0 * D, rows, P, r0);
         }
         {   GemmParams p = gemm(ctx->att, D, l.co, D); p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D; launch_gemm(p, s); }
         launch_layernorm(ctx->x, l.ln3.g, l.ln3.b, ctx->xn, nullptr, M, D, s);
@@ -1169,21 +1196,16 @@ extern "C" int mw_profile_cross_attention(mw_ctx* ctx, int batch, int iters, flo
     if (ctx->enc_batch != batch) return fail(ctx, MW_ERR_STATE, "mw_profile_cross_attention: encode this batch first");
     HIPCHK(hipSetDevice(ctx->device));
     const mw_model_desc& d = ctx->d;
-    const size_t cross_layer = (size_t)ctx->max_batch * d.n_audio_ctx * d.d_model;
     // cycle over the layers so that successive launches read different cache regions, as in a real step
-    launch_dec_cross_attn(ctx->dq, ctx->crossK, ctx->crossV, ctx->datt, batch, d.n_heads, d.n_audio_ctx, ctx->xpartial,
-                          ctx->xtickets, ctx->stream);
+    cross_attention(ctx, 0, ctx->dq, ctx->datt, batch);
     HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
-    for (int i = 0; i < iters; ++i) {
-        const int li = i % d.dec_layers;
-        launch_dec_cross_attn(ctx->dq, ctx->crossK + li * cross_layer, ctx->crossV + li * cross_layer, ctx->datt, batch,
-                              d.n_heads, d.n_audio_ctx, ctx->xpartial, ctx->xtickets, ctx->stream);
-    }
+    for (int i = 0; i < iters; ++i) cross_attention(ctx, i % d.dec_layers, ctx->dq, ctx->datt, batch);
     HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[4]));
     *mean_ms = ms / iters;
-    *bytes_per_launch = 2.0 * batch * d.n_audio_ctx * (double)d.d_model * 2.0;    // K and V, fp16
+    *bytes_per_launch = ctx->kv8 ? 2.0 * batch * d.n_audio_ctx * ((double)d.d_model + 4.0 * d.n_heads)     // K and V: codes + row scales
+                                 : 2.0 * batch * d.n_audio_ctx * (double)d.d_model * 2.0;                // K and V, fp16
     return MW_OK;
 }

@@ -663,6 +663,160 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
     }
 }
 
+// ------------------------------------------------------------------ cross-attention over an e4m3 cache
+// The cross-attention of dec_attn_kernel (S key ranges per (query row, head), ticket-ordered merge) over K/V kept
+// as e4m3 codes [B][H][T][64] with one fp32 scale per row: 64 + 4 bytes per row instead of 128.
+// score = (q . codes) * k_scale, output += p * v_scale * codes, everything in fp32 after an exact in-register
+// expansion of the codes.
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void e4m3x8_to_f32(const uint2& w, float (&f)[8]) {
+    const unsigned u[2] = {w.x, w.y};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float2v lo = __builtin_amdgcn_cvt_pk_f32_fp8(u[d], false);
+        const float2v hi = __builtin_amdgcn_cvt_pk_f32_fp8(u[d], true);
+        f[4 * d] = lo[0]; f[4 * d + 1] = lo[1]; f[4 * d + 2] = hi[0]; f[4 * d + 3] = hi[1];
+    }
+}
+
+// Thread layout as in dec_attn_kernel: 8 adjacent lanes per row (8 codes = 8 bytes each), RPT rows per thread
+// (row = group + NG*i), the same number of load instructions as the fp16 form at half the bytes each; the
+// register budget (<= 96) keeps five workgroups per CU, so the 5 * 256 workgroups of a batch-16 launch are all
+// resident at once.
+template <int NT, int RPT, int S, bool GRP>
+__global__ __launch_bounds__(NT, 5) void cross_attn8_kernel(const f16* __restrict__ q, const uint8_t* __restrict__ kc,
+                                                         const uint8_t* __restrict__ vc, const float* __restrict__ ks,
+                                                         const float* __restrict__ vs, f16* __restrict__ out, int H, int T,
+                                                         float* __restrict__ partial, int* __restrict__ tickets, int kv_div,
+                                                         int row0) {
+    constexpr int NG = NT / 8;            // row groups
+    constexpr int NWV = NT / 64;
+    __shared__ float part[NWV][64];
+    __shared__ float red[2 * NWV];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x / S, split = blockIdx.x % S;
+    const int per = (T + S - 1) / S;
+    const int t0 = split * per;
+    const int n = min(T, t0 + per) - t0;
+    const int rg = tid >> 3, dc = tid & 7;
+    long bh_kv = bh;
+    if constexpr (GRP) {
+        const int seq = bh / H;
+        bh_kv = (long)((seq + row0) / kv_div) * H + (bh - seq * H);
+    }
+    const uint8_t* kb = kc + (bh_kv * T + t0) * 64 + dc * 8;
+    const uint8_t* vb = vc + (bh_kv * T + t0) * 64 + dc * 8;
+    const float* ksb = ks + bh_kv * T + t0;
+    const float* vsb = vs + bh_kv * T + t0;
+
+    uint2 kv[RPT];
+    float rs[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = min(rg + NG * i, n - 1);
+        kv[i] = *reinterpret_cast<const uint2*>(kb + (long)r * 64);
+        rs[i] = ksb[r];
+    }
+    float qv[8];
+    {
+        const half8 qh = *reinterpret_cast<const half8*>(q + (long)bh * 64 + dc * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j];
+    }
+    float sv[RPT];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        float f[8];
+        e4m3x8_to_f32(kv[i], f);
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += qv[j] * f[j];
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        d += __shfl_xor(d, 4);
+        sv[i] = (rg + NG * i < n) ? d * rs[i] : -3.0e38f;
+        mx = fmaxf(mx, sv[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = min(rg + NG * i, n - 1);
+        kv[i] = *reinterpret_cast<const uint2*>(vb + (long)r * 64);
+        rs[i] = vsb[r];
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, red[w]);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        sv[i] = __expf(sv[i] - mx);                 // masked rows: exp(-huge) = 0
+        sum += sv[i];
+    }
+    sum = wave_sum(sum) * 0.125f;                   // each row's score is held by its 8 lanes
+    if (lane == 0) red[NWV + wave] = sum;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        float f[8];
+        e4m3x8_to_f32(kv[i], f);
+        const float w = sv[i] * rs[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += w * f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a = acc[j];
+        a += __shfl_xor(a, 8);
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        acc[j] = a;
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[wave][lane * 8 + j] = acc[j];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float o = 0.f, l = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) { o += part[w][lane]; l += red[NWV + w]; }
+    // hand-off and merge: as in dec_attn_kernel
+    float* mine = partial + ((long)bh * S + split) * kPartStride;
+    __hip_atomic_store(mine + 2 + lane, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+        __hip_atomic_store(mine, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + bh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __shfl(ticket, 0);
+    if (ticket != S - 1) return;
+    float pm[S], pl[S], po[S];
+    float gm = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const float* src = partial + ((long)bh * S + i) * kPartStride;
+        pm[i] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pl[i] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        po[i] = __hip_atomic_load(src + 2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gm = fmaxf(gm, pm[i]);
+    }
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const float w = __expf(pm[i] - gm);
+        L += w * pl[i];
+        O += w * po[i];
+    }
+    out[(long)bh * 64 + lane] = (f16)(O / L);
+    if (lane == 0) __hip_atomic_store(tickets + bh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------ token bookkeeping
 // dec_init: position 0, first forced token embedded.  dec_finalize (one workgroup per sequence):
 // choose the next token (forced while inside the prompt, else the arg-max candidate), apply the
@@ -1197,6 +1351,17 @@ void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out
 
 void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s, int rep, int* src_rows) {
     hipLaunchKernelGGL(prefill_last_rows_kernel, dim3(B), dim3(256), 0, s, x, dx, P, D, st, rep, src_rows);
+}
+
+void launch_dec_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
+                            int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div, int row0) {
+    // 4 key ranges of 375 frames; 256 threads = 32 row groups x 12 rows = 384 >= 375
+    if (kv_div > 1)
+        hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, true>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, k8, v8, ks, vs,
+                           out, H, T, partial, tickets, kv_div, row0);
+    else
+        hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, false>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, k8, v8, ks, vs,
+                           out, H, T, partial, tickets, 1, 0);
 }
 
 void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s) {

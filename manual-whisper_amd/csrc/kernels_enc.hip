@@ -63,16 +63,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-// e4m3 (OCP, max 448) pair conversion: round to nearest even in hardware; the inputs are clamped
-// to the finite range first so that no overflow encoding can appear.
-__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
-    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
-    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    return (unsigned)w;
-}
-
 // LayerNorm whose output feeds an fp8 product: the normalised row is quantised to e4m3 with one
 // scale per row, scale = max|y| / 448 (1 for an all-zero row), y8 = round(y / scale).  Same
 // statistics as layernorm_kernel; the row never leaves the registers.

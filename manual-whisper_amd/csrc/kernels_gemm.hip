@@ -91,7 +91,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, float4v (&a
         bv[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (SC > 0) wsc[i] = *reinterpret_cast<const float4*>(p.w_scale + nc);
         sc[i] = n < p.scale_ncols ? p.scale : 1.0f;
-        if constexpr (OUT == OUT_F16 || OUT == OUT_RESID_F32) {
+        if constexpr (OUT == OUT_F16 || OUT == OUT_RESID_F32 || OUT == OUT_KV_SPLIT8) {
             col[i] = nc; sec[i] = 0;
         } else {
             sec[i] = nc / p.D;
@@ -100,6 +100,44 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, float4v (&a
             if (OUT == OUT_QKV_SPLIT && sec[i] == 2) col[i] = ((long)hh * 64 + e) * p.Tpad;       // V^T [B][H][64][Tpad]
             else col[i] = (long)hh * p.T * 64 + e;                                                // [B][H][T][64]
         }
+    }
+    if constexpr (OUT == OUT_KV_SPLIT8) {
+        // The wave's 64 columns n0 + wn*64 .. +63 are one head of K (first D columns) or of V: the row of 64 gets
+        // one scale (max|.| / 448 over the 4 subtiles of this lane and the 4 lanes that share the row).
+        const int nb = n0 + wn * 64;
+        const bool head_ok = nb < p.N;                          // N = 2D is a multiple of 64
+        const int nc = head_ok ? nb : 0;
+        const int secw = nc / p.D, hh = (nc - secw * p.D) >> 6;
+        uint8_t* cb = secw == 0 ? p.k8 : p.v8;
+        float* sb = secw == 0 ? p.ks : p.vs;
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+            const int m = m0 + wm * MI * 16 + j * 16 + fr;
+            const bool m_ok = m < p.M;
+            const float asc = p.a_scale[m_ok ? m : 0];
+            float4v v[4];
+            float mx = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = acc[i][j];
+                v[i][0] = v[i][0] * (asc * wsc[i].x) + bv[i].x; v[i][1] = v[i][1] * (asc * wsc[i].y) + bv[i].y;
+                v[i][2] = v[i][2] * (asc * wsc[i].z) + bv[i].z; v[i][3] = v[i][3] * (asc * wsc[i].w) + bv[i].w;
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[i][0]), fabsf(v[i][1]))), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float scl = mx > 0.f ? mx / 448.f : 1.f;
+            if (m_ok && head_ok) {
+                const int bb = m / p.T, tt = m - bb * p.T;
+                const long rowi = ((long)bb * p.H + hh) * p.T + tt;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<unsigned*>(cb + rowi * 64 + i * 16 + 4 * fg) =
+                        pack4_e4m3(v[i][0] / scl, v[i][1] / scl, v[i][2] / scl, v[i][3] / scl);
+                if (fg == 0) sb[rowi] = scl;
+            }
+        }
+        return;
     }
     const bool flat = p.c_rows_per_batch >= p.M;
 #pragma unroll
@@ -152,6 +190,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
         switch (p.out_mode) {
             case OUT_F16: gemm_epilogue_t<MI, OUT_F16, true, 2>(p, acc, m0, n0, wm, wn, fr, fg); break;
             case OUT_QKV_SPLIT: gemm_epilogue_t<MI, OUT_QKV_SPLIT, false, 2>(p, acc, m0, n0, wm, wn, fr, fg); break;
+            case OUT_KV_SPLIT8: gemm_epilogue_t<MI, OUT_KV_SPLIT8, false, 2>(p, acc, m0, n0, wm, wn, fr, fg); break;
             default: gemm_epilogue_t<MI, OUT_KV_SPLIT, false, 2>(p, acc, m0, n0, wm, wn, fr, fg); break;
         }
         return;

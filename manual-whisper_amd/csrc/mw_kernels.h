@@ -19,6 +19,16 @@ constexpr int kHop = 160;
 constexpr int kFreqPad = 256;   // 201 DFT bins padded to 8 tiles of 32
 constexpr int kHeadDim = 64;
 
+// e4m3 (OCP, max 448) conversion of four floats, round to nearest even in hardware; the inputs are clamped to
+// the finite range first so that no overflow encoding can appear.  Byte i of the result is value i.
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
 // ---------------------------------------------------------------- log-mel
 struct MelTables {
     const float* basis_cos;   // [400][256]  hann[n]*cos(2*pi*f*n/400), zero for f >= 201
@@ -37,7 +47,7 @@ void launch_mel_import(const float* mel, int B, int n_mels, f16* melT, hipStream
 void launch_frame_energy(const float* pcm, long n, int frame, int hop, float* out, long n_frames, hipStream_t s);
 
 // ---------------------------------------------------------------- big GEMM (encoder, cross K/V)
-enum GemmOut { OUT_F16 = 0, OUT_RESID_F32 = 1, OUT_QKV_SPLIT = 2, OUT_KV_SPLIT = 3 };
+enum GemmOut { OUT_F16 = 0, OUT_RESID_F32 = 1, OUT_QKV_SPLIT = 2, OUT_KV_SPLIT = 3, OUT_KV_SPLIT8 = 4 };
 struct GemmParams {
     // C[m][n] = epilogue( sum_k A[m][k] * W[n][k] ), fp16 operands, fp32 accumulate
     const f16* A; long lda; int a_rows_per_batch; long a_batch_stride;
@@ -55,6 +65,8 @@ struct GemmParams {
     // OUT_QKV_SPLIT, OUT_KV_SPLIT.  f8 == 0 with w_scale != null: fp16 operands, columns scaled by
     // w_scale[n] before the bias (W holds unscaled fp8 codes expanded to fp16); OUT_RESID_F32 without GELU, or OUT_F16.
     int f8; const float* a_scale; const float* w_scale;
+    // OUT_KV_SPLIT8 (f8 products only): k, v as e4m3 codes [B][H][T][64] with one scale per (b, h, t) row of 64
+    uint8_t* k8; uint8_t* v8; float* ks; float* vs;
 };
 void launch_gemm(const GemmParams& p, hipStream_t s);
 
@@ -138,6 +150,9 @@ constexpr int kXattnSplit = 4;
 // recording; the prompt positions of one sequence).  row0: index of this launch's first row in the whole list.
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
                            int* tickets, hipStream_t s, int kv_div = 1, int row0 = 0);
+// The same over an e4m3 cache: k8, v8 [B][H][T][64] codes, ks, vs [B][H][T] row scales
+void launch_dec_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
+                            int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div = 1, int row0 = 0);
 constexpr int kPrefillSlabRows = 256;      // query rows per cross-attention launch of the prompt prefill
 
 struct FinalizeParams {

@@ -34,9 +34,12 @@ class Engine:
 
     ``weight_format``: ``"f16"``, or ``"fp8"`` (Linear weights of the layers kept as OCP e4m3 codes with a
     scale per output row, quantised as they are loaded; see ``mw_weight_format`` in include/mwhip.h).
+    ``kv_format``: ``"f16"``, or ``"fp8"`` (the cached cross-attention K/V as e4m3 codes with a scale per row
+    of 64; fp8 weights only; ``mw_kv_format``).
     """
 
-    def __init__(self, dims: WhisperDims, device: int = 0, max_batch: int = 16, weight_format: str = "f16"):
+    def __init__(self, dims: WhisperDims, device: int = 0, max_batch: int = 16, weight_format: str = "f16",
+                 kv_format: str = "f16"):
         self._lib = _lib.load()
         self.dims = dims
         self.device = device
@@ -44,9 +47,12 @@ class Engine:
         self.opts: Optional[DecodeOptions] = None
         if weight_format not in _lib.WEIGHT_FORMATS:
             raise EngineError(f"weight_format={weight_format!r}: expected one of {sorted(_lib.WEIGHT_FORMATS)}")
-        self.weight_format = weight_format
+        if kv_format not in _lib.KV_FORMATS:
+            raise EngineError(f"kv_format={kv_format!r}: expected one of {sorted(_lib.KV_FORMATS)}")
+        self.weight_format, self.kv_format = weight_format, kv_format
         desc = _lib.ModelDesc(dims.n_mels, dims.d_model, dims.n_heads, dims.enc_layers, dims.dec_layers,
-                              dims.ffn_dim, dims.vocab, dims.n_audio_ctx, dims.n_text_ctx, _lib.WEIGHT_FORMATS[weight_format])
+                              dims.ffn_dim, dims.vocab, dims.n_audio_ctx, dims.n_text_ctx, _lib.WEIGHT_FORMATS[weight_format],
+                              _lib.KV_FORMATS[kv_format])
         h = C.c_void_p()
         rc = self._lib.mw_create(C.byref(desc), device, max_batch, C.byref(h))
         if rc != 0:
@@ -61,7 +67,7 @@ class Engine:
         self._check(self._lib.mw_fork(self._h, C.byref(h)), "mw_fork")
         child = object.__new__(Engine)
         child._lib, child.dims, child.device, child.max_batch = self._lib, self.dims, self.device, self.max_batch
-        child.weight_format = self.weight_format
+        child.weight_format, child.kv_format = self.weight_format, self.kv_format
         child.opts = self.opts
         child._h = h
         child._parent = self          # keeps the weights alive

@@ -35,7 +35,8 @@ from .scheduler import EnginePool, batches_of, split_chunks
 
 _GPU_NAMES = ("cuda", "hip", "gpu", "rocm")
 _FP16_NAMES = ("float16", "fp16", "half", "default")
-_FP8_NAMES = ("float8", "fp8", "float8_e4m3", "float8_e4m3fn")
+_FP8_NAMES = ("float8", "fp8", "float8_e4m3", "float8_e4m3fn", "float8_kv8")
+_KV8_NAMES = ("float8_kv8",)
 
 
 def _dims_from_config(path: str) -> WhisperDims:
@@ -147,7 +148,8 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
         raise EngineError(f"device={device!r}: this engine runs on an MI355X GPU only (use 'cuda'); there is no CPU path")
     if compute_type not in _FP16_NAMES + _FP8_NAMES:
         raise EngineError(f"compute_type={compute_type!r} is not available: 'float16' (fp16 weights, fp32 accumulation) or "
-                          "'float8' (e4m3 Linear weights with a scale per output row, quantised at load)")
+                          "'float8' (e4m3 Linear weights with a scale per output row, quantised at load) or 'float8_kv8' "
+                          "(the same plus an e4m3 cross-attention K/V cache)")
     if task != "transcribe":
         raise EngineError("only task='transcribe' is implemented")
     asr_options = dict(asr_options or {})
@@ -178,7 +180,8 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
         if os.path.exists(tok):
             from tokenizers import Tokenizer
             tokenizer = Tokenizer.from_file(tok)
-    engine = Engine(dims, device=device_index, max_batch=max_batch, weight_format="fp8" if compute_type in _FP8_NAMES else "f16")
+    engine = Engine(dims, device=device_index, max_batch=max_batch, weight_format="fp8" if compute_type in _FP8_NAMES else "f16",
+                    kv_format="fp8" if compute_type in _KV8_NAMES else "f16")
     engine.load_weights(weights)
     del weights
     return Model(engine, dims, language or "zh", tokenizer, asr_options.get("initial_prompt"), vad_options,

@@ -113,6 +113,8 @@ def log_mel(pcm: np.ndarray, n_mels: int) -> np.ndarray:
 # (tests/test_oracle.py), and the HIP engine must reproduce THIS restatement.
 #   weights:     per output row, scale = max|w| / 448 (1 for a zero row), code = rne_e4m3(w / scale);
 #                the Linear weights of the encoder and decoder layers only.
+#   K/V cache:   (kv_format "fp8") the cached cross-attention keys and values, one scale per row of 64
+#                (sequence, head, frame).
 #   activations: the rows a LayerNorm hands to an encoder Linear (QKV, MLP in) and the encoder output
 #                rows handed to the cross K/V projection are quantised the same way, one scale per row.
 E4M3_MAX = np.float32(448.0)
@@ -201,8 +203,9 @@ class WhisperOracle:
     ``model.decoder.embed_tokens.weight`` — modeling_whisper.py:965,970,1080).
     """
 
-    def __init__(self, dims, weights: dict, weight_format: str = "f16"):
-        assert weight_format in ("f16", "fp8")
+    def __init__(self, dims, weights: dict, weight_format: str = "f16", kv_format: str = "f16"):
+        assert weight_format in ("f16", "fp8") and kv_format in ("f16", "fp8")
+        self.kv8 = kv_format == "fp8"
         self.d = dims
         self.w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
         self.fp8 = weight_format == "fp8"
@@ -274,6 +277,8 @@ class WhisperOracle:
             p = f"model.decoder.layers.{i}.encoder_attn"
             k = _split_heads(linear(enc, w[p + ".k_proj.weight"]), self.H)
             v = _split_heads(linear(enc, w[p + ".v_proj.weight"], w[p + ".v_proj.bias"]), self.H)
+            if self.kv8:                                          # e4m3 cache: one scale per (sequence, head, frame) row of 64
+                k, v = fake_quant_rows_e4m3(k), fake_quant_rows_e4m3(v)
             out.append((k, v))
         return out
 

@@ -24,7 +24,7 @@ import pytest
 
 import manual_whisper_amd as mw
 from manual_whisper_amd import synth
-from manual_whisper_amd.decode_options import synthetic_options
+from manual_whisper_amd.decode_options import DecodeOptions, synthetic_options
 from oracle.whisper_ref import WhisperOracle, log_mel
 
 from test_gpu_parity import ENC_ATOL, LOGIT_ATOL, assert_ids_match_up_to_ties
@@ -174,5 +174,100 @@ def test_config5_large_v3_fp8_one_chunk_vs_oracle():
         hi, _ = eng.transcribe_batch(pcm[16:])
         assert (la == 12).all() and (a[:16] == lo).all() and (a[16:] == hi).all()
         assert len({tuple(r) for r in a}) > 1
+    finally:
+        eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# e4m3 cross-attention K/V cache (kv_format="fp8")
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["micro", "tiny"])
+def test_kv8_decoder_vs_oracle(name):
+    """The projection's epilogue quantises each (sequence, head, frame) row of 64 keys / values; the decode and
+    prefill cross-attention read the codes.  With the oracle on the engine's own encoder output the projected
+    values agree to fp32 rounding, so the codes are the same and the fp16 tolerances apply."""
+    from manual_whisper_amd.engine import Engine
+    dims = mw.get_dims(name)
+    w = synth.make_weights_np(dims, 1234)
+    eng = Engine(dims, 0, 32, weight_format="fp8", kv_format="fp8")
+    eng.load_weights(w)
+    try:
+        B = 3
+        pcm = synth.make_pcm_np(B, 91)
+        orc = WhisperOracle(dims, w, weight_format="fp8", kv_format="fp8")
+        base = synthetic_options(dims, max_new=10)
+        eng.set_decode_options(base)
+        eng.logmel(pcm, want_output=False)
+        enc = eng.encode(B)
+        rng = np.random.default_rng(8)
+        toks = np.concatenate([np.tile(np.asarray(base.prompt)[None], (B, 1)), rng.integers(0, dims.vocab, size=(B, 6))], axis=1).astype(np.int32)
+        got = eng.decode_forced(toks)
+        want = orc.forced_logits(enc, toks)
+        assert np.abs(got - want).max() < LOGIT_ATOL
+        far = WhisperOracle(dims, w, weight_format="fp8").forced_logits(enc, toks)          # fp16 cache: measurably further away
+        assert np.abs(got - far).max() > 3 * np.abs(got - want).max()
+        # greedy, stepping and prefilled, a long prompt (the grouped form of the kernel: query rows sharing a cache)
+        prompt = tuple(int(t) for t in rng.integers(0, dims.vocab, size=29)) + (base.prompt[-1],)
+        opts = DecodeOptions(prompt, base.eot, base.suppress, base.begin_suppress, 10)
+        eng.set_decode_options(opts)
+        wi, wl, wlog = orc.greedy(enc, list(prompt), 10, opts.eot, opts.effective_suppress(), opts.begin_suppress, return_logits=True)
+        for prefill in (0, 1):
+            eng.set_option("prefill", prefill)
+            ids, lens, logits = eng.decode_greedy(B, want_logits=True)
+            assert np.abs(logits[0] - wlog[0]).max() < LOGIT_ATOL
+            assert_ids_match_up_to_ties(ids, wi, orc.last_margins)
+        # a beam of one is greedy; five beams share each recording's cache rows
+        b1 = eng.decode_beam(B, 1)
+        assert (b1[0] == ids).all()
+        b5 = eng.decode_beam(B, 5, 1.0, want_hypotheses=True)
+        w5 = orc.beam_search(enc, list(prompt), 10, opts.eot, 5, 1.0, opts.suppress, opts.begin_suppress)
+        for a in range(B):
+            if orc.last_beam_margins[a] > 4e-2:
+                assert {tuple(int(x) for x in b5[3][a, c, : b5[4][a, c]]) for c in range(5)} == {tuple(t) for t, _ in w5[3][a]}
+        # batch position and size do not matter
+        eng.set_decode_options(base)
+        pcm32 = synth.make_pcm_np(32, 17)
+        full, _ = eng.transcribe_batch(pcm32)
+        for n in (1, 17):
+            part, _ = eng.transcribe_batch(pcm32[:n])
+            assert (part == full[:n]).all(), n
+    finally:
+        eng.close()
+
+
+def test_kv8_needs_fp8_weights():
+    from manual_whisper_amd.engine import Engine, EngineError
+    with pytest.raises(EngineError, match="MW_KV_FP8"):
+        Engine(mw.get_dims("micro"), 0, 1, weight_format="f16", kv_format="fp8")
+
+
+def test_config5_large_v3_kv8_one_chunk_vs_oracle():
+    import torch
+    from manual_whisper_amd.engine import Engine
+    dims = mw.get_dims("large-v3")
+    wt = synth.make_weights_torch(dims, 1234, torch.device("cuda", 0))
+    eng = Engine(dims, 0, 32, weight_format="fp8", kv_format="fp8")
+    eng.load_weights(wt)
+    orc = WhisperOracle(dims, {k: v.float().cpu().numpy() for k, v in wt.items()}, weight_format="fp8", kv_format="fp8")
+    del wt
+    torch.cuda.empty_cache()
+    try:
+        opts = synthetic_options(dims, max_new=6, suppress_eot=True)
+        eng.set_decode_options(opts)
+        pcm = synth.make_pcm_np(1, seed=303)
+        eng.logmel(pcm, want_output=False)
+        enc = eng.encode(1)
+        ids, lens, logits = eng.decode_greedy(1, want_logits=True)
+        wi, wl, wlog = orc.greedy(enc, list(opts.prompt), opts.max_new, opts.eot, opts.effective_suppress(),
+                                  opts.begin_suppress, return_logits=True)
+        assert np.abs(logits[0] - wlog[0]).max() < 2 * LOGIT_ATOL
+        assert_ids_match_up_to_ties(ids, wi, orc.last_margins)
+        opts = synthetic_options(dims, max_new=12, suppress_eot=True)
+        eng.set_decode_options(opts)
+        pcm = synth.make_pcm_np(32, seed=505)
+        a, la = eng.transcribe_batch(pcm)
+        lo, _ = eng.transcribe_batch(pcm[:16])
+        hi, _ = eng.transcribe_batch(pcm[16:])
+        assert (la == 12).all() and (a[:16] == lo).all() and (a[16:] == hi).all()
     finally:
         eng.close()
