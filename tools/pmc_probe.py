@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development aid for hardware-counter runs: a torch-free process (MW_SYSTEM_HIP=1, system ROCm
 runtime) that runs log-mel, the encoder, cross K/V and a few large-v3 decode steps at batch 16 on
-random weights.  Used as `rocprofv3 --pmc FETCH_SIZE -- python3 tools/pmc_probe.py`, with
+random weights (MW_WEIGHTS=fp8 / MW_KV=fp8 select the e4m3 formats).  Used as `rocprofv3 --pmc FETCH_SIZE -- python3 tools/pmc_probe.py`, with
 WRITE_SIZE and the SQ / GRBM counters each in a pass of their own; tools/pmc_summary.py turns
 the per-dispatch CSVs into one table."""
 import os, sys
@@ -17,7 +17,7 @@ from manual_whisper_amd.engine import Engine
 B = 16
 dims = mw.get_dims("large-v3")
 rng = np.random.default_rng(0)
-eng = Engine(dims, 0, B)
+eng = Engine(dims, 0, B, weight_format=os.environ.get("MW_WEIGHTS", "f16"), kv_format=os.environ.get("MW_KV", "f16"))
 w = {}
 for name, shape, kind, scale in synth.tensor_specs(dims):
     n = int(np.prod(shape))
