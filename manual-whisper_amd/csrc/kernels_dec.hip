@@ -117,7 +117,8 @@ __global__ __launch_bounds__(XV > 0 ? 512 : 1024) void gemv_kernel(GemvParams p)
 #pragma unroll
         for (int r = 0; r < R; ++r) wreg[r][c] = *reinterpret_cast<const uint4*>(wp[r] + min(ks, nks - 1) * 64);
     }
-    // epilogue operands: wave r finishes row tile r
+    // epilogue operands: wave r finishes row tile r (the position too: read here, it costs no round trip of its own)
+    const int pos = (p.out_mode == GV_QKV && p.st) ? p.st->pos : 0;
     const int nl = wave * 16 + 4 * fg;
     const int n = n0 + nl;
     const bool owner = wave < R && nl < nv && n < p.N;                     // N and nv are multiples of 4
@@ -222,7 +223,6 @@ __global__ __launch_bounds__(XV > 0 ? 512 : 1024) void gemv_kernel(GemvParams p)
     if (!owner) return;
 
     // ---- epilogue: lane holds out[m][n..n+3]
-    const int pos = p.st ? p.st->pos : 0;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = t * 16 + fr;
@@ -421,6 +421,7 @@ __global__ __launch_bounds__(512) void logits_kernel(GemvParams p) {
     const f16* wp = p.W + (long)wrow * p.K + fg * 8;
     const int nks = p.K >> 5;
 
+    const int sample = p.st->pos - p.st->prompt_len;       // pos was advanced by the final LayerNorm launch
     uint4 wa[LCH], wb[LCH];
     auto wload = [&](uint4 (&dst)[LCH], int kb) {
 #pragma unroll
@@ -457,7 +458,6 @@ __global__ __launch_bounds__(512) void logits_kernel(GemvParams p) {
         if (kb + 3 * LCH < nks) wload(wb, kb + 3 * LCH);
     }
 
-    const int sample = p.st->pos - p.st->prompt_len;       // pos was advanced by the final LayerNorm launch
     const uint8_t* mask = sample <= 0 ? p.mask_first : p.mask_rest;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
