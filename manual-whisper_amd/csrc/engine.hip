@@ -778,7 +778,7 @@ static void enqueue_step_tail(mw_ctx* ctx, int B, bool want_logits, const Finali
 // One greedy step: 8 launches per layer + final norm + logits + token bookkeeping.
 static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int max_keys, const BeamParams* beam = nullptr) {
     const mw_model_desc& d = ctx->d;
-    const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, Tc = d.n_text_ctx;
+    const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, Tc = d.n_text_ctx;
     hipStream_t s = ctx->stream;
     const float qscale = 1.0f / sqrtf((float)kHeadDim);
     const size_t self_layer = (size_t)ctx->max_batch * D * Tc;
@@ -838,7 +838,7 @@ static FinalizeParams finalize_params(mw_ctx* ctx, int n_forced) {
 // first beam, `src_rows` points every beam at them, and dx gets `beam` copies of each last row.
 static int run_prefill(mw_ctx* ctx, int B, int P, int beam = 1, int* src_rows = nullptr) {
     const mw_model_desc& d = ctx->d;
-    const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, Tc = d.n_text_ctx;
+    const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, Tc = d.n_text_ctx;
     const int M = B * P;
     hipStream_t s = ctx->stream;
     const float qscale = 1.0f / sqrtf((float)kHeadDim);
