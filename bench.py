@@ -114,6 +114,35 @@ def cpu_baseline(dims, weights_np, opts, gpu_ids_fn, weight_format="f16", kv_for
     }
 
 
+def coalesced_run(args, dims, opts, dev, local_rank):
+    """The same workload with the scheduler coalescing several batches of 16 into one engine pass: the decode
+    GEMVs then stream every weight once for all of them (groups of 16 sequences inside each launch)."""
+    import torch
+    from manual_whisper_amd import synth
+    from manual_whisper_amd.engine import Engine
+    from manual_whisper_amd.scheduler import EnginePool
+    nb, ne = args.also_batch, args.also_engines
+    eng = Engine(dims, device=local_rank, max_batch=nb, weight_format=args.weights, kv_format=args.kv)
+    eng.load_weights(synth.make_weights_torch(dims, seed=1234, device=dev))
+    eng.set_decode_options(opts)
+    pool = EnginePool(eng, ne)
+    pcms = [synth.make_pcm_torch(nb, seed=5000 + i, device=dev) for i in range(2)]
+    for e in pool.engines:
+        e.transcribe_batch(pcms[0])
+    pool.map([pcms[i % 2] for i in range(ne)])
+    torch.cuda.synchronize()
+    steps = 2 * ne
+    t0 = time.perf_counter()
+    pool.map([pcms[i % 2] for i in range(steps)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pool.close()
+    torch.cuda.empty_cache()
+    return {"value": round(steps * nb * 30.0 / dt, 2), "unit": "audio-seconds/second",
+            "workload": f"as config.workload, but {nb} chunks ({nb // 16} batches of 16) per engine pass, {ne} engines in flight, "
+                        f"{steps} passes timed", "ms_per_16_chunks": round(dt / (steps * nb / 16) * 1e3, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,6 +154,10 @@ def main():
     ap.add_argument("--weights", choices=("f16", "fp8"), default="f16",
                     help="fp8: BASELINE configs[4] (e4m3 Linear weights, fp8 MFMA in the encoder); the default is the metric's configs[2]")
     ap.add_argument("--kv", choices=("f16", "fp8"), default="f16", help="fp8: e4m3 cross-attention K/V cache (needs --weights fp8)")
+    ap.add_argument("--also-batch", type=int, default=64,
+                    help="N=1 only: after the main measurement, the same chunks with this many per engine pass (batches of 16 coalesced "
+                         "by the scheduler into one lock-step decode; 0 = skip), reported under 'coalesced'")
+    ap.add_argument("--also-engines", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="30 s chunks per step per GPU (configs[4] uses 32)")
     args = ap.parse_args()
 
@@ -232,6 +265,8 @@ def main():
         out["whole_run"] = {"hbm_GBps_per_gpu": round(hb / world, 1), "hbm_frac": round(hb / world / HBM_PEAK_GBS, 4),
                             "mfma_TFLOPs_per_gpu": round(fl / world, 1), "mfma_frac": round(fl / world / MFMA_F16_PEAK_TFLOPS, 4),
                             "step_floor_over_step": round(sr["sum_of_stage_floors_ms"] / (elapsed / args.steps * 1e3), 4)}
+        if world == 1 and args.also_batch > batch:
+            out["coalesced"] = coalesced_run(args, dims, opts, dev, local_rank)
         if weights_np is not None:
             def gpu_ids(pcm, n_new):
                 o = synthetic_options(dims, max_new=n_new, suppress_eot=True)

@@ -50,7 +50,7 @@ def transcribe_audio(audio_file, hf_token=None):
     say(f"📝 加载 Whisper {MODEL_SIZE} 模型...")
     model = load_model(MODEL_SIZE, DEVICE, device_index=local_rank, compute_type=COMPUTE_TYPE, language="zh",
                        asr_options={"initial_prompt": INITIAL_PROMPT}, vad_options=VAD_OPTIONS,
-                       max_batch=min(32, max(1, BATCH_SIZE)), n_engines=int(os.environ.get("MW_ENGINES", "2")))
+                       max_batch=min(128, max(1, BATCH_SIZE)), n_engines=int(os.environ.get("MW_ENGINES", "2")))
     say(f"   模型加载耗时: {time.time() - t:.1f}s")
     say("🔊 加载音频...")
     audio = load_audio(audio_file)

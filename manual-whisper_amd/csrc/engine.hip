@@ -269,7 +269,8 @@ static int alloc_work(mw_ctx* ctx) {
     ALLOC(ctx->mask_first, (size_t)d.vocab, true); ALLOC(ctx->mask_rest, (size_t)d.vocab, true);
     const size_t xrows = std::max<size_t>(B, kPrefillSlabRows);      // query rows one cross-attention launch may carry
     ALLOC(ctx->xpartial, xrows * H * kXattnSplit * 68); ALLOC(ctx->xtickets, xrows * H, true);
-    ALLOC(ctx->skpartial, splitk_partial_floats(D)); ALLOC(ctx->sktickets, splitk_groups(D), true);
+    const size_t seq_groups = (B + 15) / 16;                          // batches beyond 32 run as groups of 16 inside a launch
+    ALLOC(ctx->skpartial, splitk_partial_floats(D) * seq_groups); ALLOC(ctx->sktickets, splitk_groups(D) * seq_groups, true);
     ctx->forced_cap = d.n_text_ctx;
     ALLOC(ctx->forced, B * (size_t)ctx->forced_cap);
     ALLOC(ctx->out_ids, B * (size_t)d.n_text_ctx); ALLOC(ctx->out_len, B); ALLOC(ctx->finished, B);
@@ -284,7 +285,7 @@ extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, m
     if (d.d_model % 32 || d.ffn_dim % 32 || d.d_model > 2048 || d.ffn_dim > 5120) { g_create_error = "mw_create: d_model/ffn_dim must be multiples of 32, d_model <= 2048, ffn_dim <= 5120"; return MW_ERR_ARG; }
     if (d.n_mels % 8 || d.n_mels > 128 || d.n_mels <= 0) { g_create_error = "mw_create: n_mels must be a multiple of 8, <= 128"; return MW_ERR_ARG; }
     if (d.n_audio_ctx != kFrames / 2 || d.n_text_ctx <= 0 || d.n_text_ctx > 448) { g_create_error = "mw_create: n_audio_ctx must be 1500 and n_text_ctx <= 448"; return MW_ERR_ARG; }
-    if (max_batch < 1 || max_batch > 32) { g_create_error = "mw_create: max_batch must be in 1..32"; return MW_ERR_ARG; }
+    if (max_batch < 1 || max_batch > 128) { g_create_error = "mw_create: max_batch must be in 1..128"; return MW_ERR_ARG; }
     if (d.vocab < 16 || d.enc_layers < 1 || d.dec_layers < 1) { g_create_error = "mw_create: bad vocab/layer count"; return MW_ERR_ARG; }
     if (d.weight_format != MW_WEIGHTS_F16 && d.weight_format != MW_WEIGHTS_FP8) { g_create_error = "mw_create: weight_format must be MW_WEIGHTS_F16 or MW_WEIGHTS_FP8"; return MW_ERR_ARG; }
     if (d.kv_format != MW_KV_F16 && d.kv_format != MW_KV_FP8) { g_create_error = "mw_create: kv_format must be MW_KV_F16 or MW_KV_FP8"; return MW_ERR_ARG; }

@@ -49,6 +49,22 @@ __device__ __forceinline__ void e4m3x16_to_f16(const uint4& w, half8& lo, half8&
     hi = half8{h[4][0], h[4][1], h[5][0], h[5][1], h[6][0], h[6][1], h[7][0], h[7][1]};
 }
 
+// Batches beyond one MFMA row tile set (16*MT sequences) run as GROUPS: the same launch carries one copy of
+// its workgroups per group of 16*MT sequences (grid y, or z for the split-K form), all reading the same weight
+// rows at the same time, so HBM sees the weights once and the other groups hit L2.  A group's workgroups see
+// a parameter block whose row-indexed pointers start at the group's first sequence.
+__device__ __forceinline__ void group_view(GemvParams& p, int g, int rows_per_group) {
+    const long r0 = (long)g * rows_per_group;
+    p.B = min(rows_per_group, p.B - (int)r0);
+    if (p.x32) p.x32 += r0 * p.K;
+    if (p.xin16) p.xin16 += r0 * p.K;
+    if (p.out16) p.out16 += r0 * (p.out_mode == GV_QKV ? p.D : p.N);
+    if (p.out32) p.out32 += r0 * p.N;
+    if (p.kcache) { p.kcache += r0 * p.H * p.Tctx * 64; p.vcache += r0 * p.H * p.Tctx * 64; }
+    if (p.part_val) { p.part_val += r0 * p.n_parts; p.part_idx += r0 * p.n_parts; }
+    if (p.sk_partial) { p.sk_partial += (long)g * p.sk_partial_floats; p.sk_tickets += (long)g * p.sk_groups; }
+}
+
 // ------------------------------------------------------------------ skinny GEMM (weights streamed once)
 // out[b][n] = epi( sum_k X[b][k] * W[n][k] ),  b < B <= 16*MT.
 //
@@ -70,6 +86,7 @@ __device__ __forceinline__ void e4m3x16_to_f16(const uint4& w, half8& lo, half8&
 template <int MT, int KPW, int XV, int R, bool W8>
 __global__ __launch_bounds__(XV > 0 ? 512 : 1024) void gemv_kernel(GemvParams p) {      // the fused form always runs 512 threads
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gridDim.y > 1) group_view(p, blockIdx.y, 16 * MT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NW = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -276,6 +293,7 @@ __global__ __launch_bounds__(kSplitKWaves * 64) void gemv_splitk_kernel(GemvPara
     constexpr int NW = kSplitKWaves, NT = R * MT;       // NT accumulator tiles per wave
     constexpr int KSTEP = W8 ? 64 : 32, XF = W8 ? 2 : 1;   // as in gemv_kernel
     __shared__ float4v red[NW][NT][64];
+    if (gridDim.z > 1) group_view(p, blockIdx.z, 16 * MT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int S = gridDim.y, split = blockIdx.y, rg = blockIdx.x;
@@ -409,6 +427,7 @@ constexpr int LCH = 8;
 template <int MT>
 __global__ __launch_bounds__(512) void logits_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gridDim.y > 1) group_view(p, blockIdx.y, 16 * MT);
     f16* xs = reinterpret_cast<f16*>(smem);                                // [16*MT][K+8]
     const int ldx = p.K + 8;
     float* cand_v = reinterpret_cast<float*>(smem + (size_t)16 * MT * ldx * 2);   // [8][16*MT]
@@ -1144,7 +1163,7 @@ template <int MT, int KPW, int XV, int R, bool W8>
 void launch_gemv_r(const GemvParams& p, int nw, hipStream_t s) {
     size_t lds = (size_t)nw * R * MT * 64 * 16;
     if (XV > 0) lds += (size_t)2 * p.K * 4 + (size_t)16 * MT * (p.K + 8) * 2;
-    hipLaunchKernelGGL((gemv_kernel<MT, KPW, XV, R, W8>), dim3((p.N + p.nv - 1) / p.nv), dim3(nw * 64), lds, s, p);
+    hipLaunchKernelGGL((gemv_kernel<MT, KPW, XV, R, W8>), dim3((p.N + p.nv - 1) / p.nv, (p.B + 16 * MT - 1) / (16 * MT)), dim3(nw * 64), lds, s, p);
 }
 template <int MT, int KPW, int XV, bool W8>
 void launch_gemv_t(const GemvParams& p, int nw, hipStream_t s) {
@@ -1240,7 +1259,7 @@ bool launch_splitk_r(const GemvParams& p, int S, hipStream_t s) {
     const int ks_per = (nks + S - 1) / S;
     S = (nks + ks_per - 1) / ks_per;                    // drop ranges that would be empty
     const int kpw = (ks_per + kSplitKWaves - 1) / kSplitKWaves;
-    const dim3 grid(p.N / (16 * R), S), block(kSplitKWaves * 64);
+    const dim3 grid(p.N / (16 * R), S, (p.B + 16 * MT - 1) / (16 * MT)), block(kSplitKWaves * 64);
     switch (kpw) {
 #define MW_SK_CASE(KPW) case KPW: hipLaunchKernelGGL((gemv_splitk_kernel<MT, KPW, R, W8>), grid, block, 0, s, p, ks_per); return true;
         MW_SK_CASE(1) MW_SK_CASE(2) MW_SK_CASE(3) MW_SK_CASE(4)
@@ -1282,9 +1301,12 @@ void dec_kernels_prepare() { prepare_mt<1>(); prepare_mt<2>(); }
 
 void launch_gemv(const GemvParams& p0, hipStream_t s) {
     GemvParams p = p0;
-    const int mt = p.B <= 16 ? 1 : 2;
+    // up to 16 sequences: one row tile; up to 32: two row tiles per workgroup; beyond: groups of 16 (see group_view)
+    static const int group_from = getenv("MW_GROUP_FROM") ? atoi(getenv("MW_GROUP_FROM")) : 33;
+    static const int group_mt = getenv("MW_GROUP_MT") ? atoi(getenv("MW_GROUP_MT")) : 1;
+    const int mt = p.B <= 16 ? 1 : p.B < group_from ? 2 : group_mt;
     if (p.out_mode == GV_LOGITS) {
-        dim3 grid(gemv_logits_parts(p.N));
+        dim3 grid(gemv_logits_parts(p.N), (p.B + 16 * mt - 1) / (16 * mt));
         const size_t lds = (size_t)16 * mt * (p.K + 8) * 2 + (size_t)8 * 16 * mt * 8;
         if (mt == 1) hipLaunchKernelGGL(logits_kernel<1>, grid, dim3(512), lds, s, p);
         else hipLaunchKernelGGL(logits_kernel<2>, grid, dim3(512), lds, s, p);

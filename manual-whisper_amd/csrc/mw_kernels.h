@@ -103,7 +103,7 @@ struct DecState {          // lives in device memory; one per context
 };
 enum GemvOut { GV_F16 = 0, GV_RESID = 1, GV_QKV = 2, GV_LOGITS = 3 };
 struct GemvParams {
-    int B, N, K;
+    int B, N, K;              // B: any number of sequences; more than 32 run as groups of 16 inside the launch
     const f16* W;             // [N][K] fp16 ...
     const uint8_t* W8;        // ... or, when non-null, [N][K] OCP e4m3 codes with w_scale [N] (K % 64 == 0); not for GV_LOGITS
     const float* w_scale;
@@ -124,7 +124,8 @@ struct GemvParams {
     const uint8_t* mask_first; const uint8_t* mask_rest;
     float* part_val; int* part_idx; int n_parts;   // [B][n_parts]
     // GV_RESID, optional: scratch of the split-K form (partial tiles + one ticket per row group; the
-    // tickets must be zero before the first launch, every launch leaves them zero again)
+    // tickets must be zero before the first launch, every launch leaves them zero again); sk_partial_floats and
+    // sk_groups are the extents of ONE group of 16 (or 32) sequences, the buffers hold one such block per group
     float* sk_partial; long sk_partial_floats; int* sk_tickets; int sk_groups;
 };
 // floats / ints of split-K scratch that cover every residual projection of a model of width D

@@ -388,3 +388,37 @@ def test_prompt_prefill_matches_stepping_and_oracle(name, n_prompt, B, weight_fo
         assert (ids2 == ids1).all()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("weight_format", ["f16", "fp8"])
+def test_batches_beyond_32_run_as_groups(weight_format):
+    """Up to 128 sequences per pass: the decode GEMVs then run one copy of their workgroups per group of 16
+    sequences inside the same launch.  Ids must be those each chunk gets in a batch of 16, for full and ragged
+    group counts, greedy and (grouped sequences sharing a recording's cache) beam search."""
+    from manual_whisper_amd.engine import Engine
+    dims = mw.get_dims("micro")
+    w = synth.make_weights_np(dims, 4321)
+    eng = Engine(dims, 0, 128, weight_format=weight_format)
+    eng.load_weights(w)
+    try:
+        opts = synthetic_options(dims, max_new=10)
+        eng.set_decode_options(opts)
+        pcm = synth.make_pcm_np(100, 23)
+        want = np.concatenate([eng.transcribe_batch(pcm[a:a + 16])[0] for a in range(0, 100, 16)])
+        for n in (33, 64, 100):
+            got, lens = eng.transcribe_batch(pcm[:n])
+            assert (got == want[:n]).all(), n
+        eng.set_option("graph", 0)
+        got, _ = eng.transcribe_batch(pcm[:50])
+        assert (got == want[:50]).all()
+        eng.set_option("graph", 1)
+        # beam search: 9 recordings x 5 beams = 45 sequences (three groups, the last ragged)
+        eng.logmel(pcm[:9], want_output=False)
+        eng.encode(9, want_output=False)
+        big = eng.decode_beam(9, 5)
+        eng.logmel(pcm[3:6], want_output=False)
+        eng.encode(3, want_output=False)
+        small = eng.decode_beam(3, 5)
+        assert (big[0][3:6] == small[0]).all() and np.abs(big[2][3:6] - small[2]).max() < 1e-5
+    finally:
+        eng.close()
