@@ -7,6 +7,7 @@ Environment (reference transcribe.py:30-36 plus this engine's own knobs):
   WHISPER_MODEL  model size / local checkpoint directory / synthetic:<size> (default large-v3)
   MW_MODEL_DIR   where model-size names are looked up
   MW_ENGINES     engines in flight on the GPU (default 2)
+  MW_COALESCE    batches of BATCH_SIZE chunks joined per engine pass (default 4: passes of up to 64 chunks)
   MW_DTYPE       float16 (default) or float8 (e4m3 Linear weights quantised at load)
   HF_TOKEN       accepted for compatibility; diarization is not part of this engine
 Launched under torch.distributed.run, the chunks are sharded over the ranks and rank 0 writes the files.
@@ -27,6 +28,7 @@ DEVICE = os.environ.get("MW_DEVICE", "cuda")
 BATCH_SIZE = int(os.environ.get("BATCH_SIZE", "16"))
 COMPUTE_TYPE = os.environ.get("MW_DTYPE", "float16")
 MODEL_SIZE = os.environ.get("WHISPER_MODEL", "large-v3")
+COALESCE = max(1, int(os.environ.get("MW_COALESCE", "4")))
 HF_TOKEN = os.environ.get("HF_TOKEN")
 
 # reference transcribe.py:39-46
@@ -50,7 +52,8 @@ def transcribe_audio(audio_file, hf_token=None):
     say(f"📝 加载 Whisper {MODEL_SIZE} 模型...")
     model = load_model(MODEL_SIZE, DEVICE, device_index=local_rank, compute_type=COMPUTE_TYPE, language="zh",
                        asr_options={"initial_prompt": INITIAL_PROMPT}, vad_options=VAD_OPTIONS,
-                       max_batch=min(128, max(1, BATCH_SIZE)), n_engines=int(os.environ.get("MW_ENGINES", "2")))
+                       max_batch=min(128, max(1, BATCH_SIZE) * COALESCE), n_engines=int(os.environ.get("MW_ENGINES", "2")),
+                       coalesce=COALESCE)
     say(f"   模型加载耗时: {time.time() - t:.1f}s")
     say("🔊 加载音频...")
     audio = load_audio(audio_file)

@@ -64,7 +64,8 @@ def _load_state_dict(path: str) -> dict:
 class Model:
     def __init__(self, engine: Engine, dims: WhisperDims, language: str, tokenizer=None,
                  initial_prompt: Optional[str] = None, vad_options: Optional[dict] = None,
-                 synthetic: bool = False, max_new: int = 224, n_engines: int = 1, beam_size: int = 1, patience: float = 1.0):
+                 synthetic: bool = False, max_new: int = 224, n_engines: int = 1, beam_size: int = 1, patience: float = 1.0,
+                 coalesce: int = 1):
         self.engine, self.dims, self.language = engine, dims, language
         self.tokenizer, self.initial_prompt = tokenizer, initial_prompt
         self.vad_options = dict(vad_options or {})
@@ -72,6 +73,9 @@ class Model:
         if beam_size < 1 or beam_size > engine.max_batch:
             raise EngineError(f"beam_size={beam_size} does not fit max_batch={engine.max_batch}")
         self.beam_size, self.patience = int(beam_size), float(patience)
+        # batches of `batch_size` chunks joined per engine pass (bounded by max_batch): chunks are independent, and
+        # one pass over 64 streams the decoder weights once where four passes over 16 stream them four times
+        self.coalesce = max(1, int(coalesce))
         self.pool = EnginePool(engine, n_engines, self.beam_size, self.patience)
         self._opts_for = None
 
@@ -119,7 +123,7 @@ class Model:
         if self._opts_for != language:
             self.pool.set_decode_options(self.decode_options(language))
             self._opts_for = language
-        bs = max(1, min(int(batch_size), self.engine.max_batch // self.beam_size))
+        bs = max(1, min(int(batch_size) * self.coalesce, self.engine.max_batch // self.beam_size))
         out = []
         for ids, lens in self.pool.map([chunks[a:b] for a, b in batches_of(len(chunks), bs)]):
             out.extend(ids[i, : lens[i]].copy() for i in range(ids.shape[0]))
@@ -138,7 +142,7 @@ class Model:
 
 def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, compute_type: str = "float16",
                asr_options: Optional[dict] = None, language: Optional[str] = None, vad_options: Optional[dict] = None,
-               task: str = "transcribe", max_batch: int = 16, n_engines: int = 1, **_ignored) -> Model:
+               task: str = "transcribe", max_batch: int = 16, n_engines: int = 1, coalesce: int = 1, **_ignored) -> Model:
     """Build an engine on GPU ``device_index``.
 
     whisper_arch: a local directory in Hugging Face layout, a model size whose directory is
@@ -186,4 +190,4 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
     del weights
     return Model(engine, dims, language or "zh", tokenizer, asr_options.get("initial_prompt"), vad_options,
                  synthetic=synthetic, max_new=int(asr_options.get("max_new_tokens", 224)), n_engines=n_engines,
-                 beam_size=int(asr_options.get("beam_size", 1)), patience=float(asr_options.get("patience", 1.0)))
+                 beam_size=int(asr_options.get("beam_size", 1)), patience=float(asr_options.get("patience", 1.0)), coalesce=coalesce)

@@ -422,3 +422,20 @@ def test_batches_beyond_32_run_as_groups(weight_format):
         assert (big[0][3:6] == small[0]).all() and np.abs(big[2][3:6] - small[2]).max() < 1e-5
     finally:
         eng.close()
+
+
+def test_model_coalesces_batches_without_changing_ids():
+    """load_model(..., coalesce=4): Model.transcribe(batch_size=16) joins four batches per engine pass; the
+    segments are those of plain batches of 16."""
+    audio = synth.make_pcm_np(40, seed=77).reshape(-1)[: 16000 * (30 * 39 + 7)]      # 40 chunks, the last one 7 s
+    res = {}
+    for coalesce in (1, 4):
+        model = mw.load_model("synthetic:micro", "cuda", asr_options={"max_new_tokens": 8}, max_batch=16 * coalesce,
+                              coalesce=coalesce)
+        try:
+            res[coalesce] = model.transcribe(audio, batch_size=16)
+        finally:
+            model.close()
+    assert len(res[1]["segments"]) == 40
+    assert [s["tokens"] for s in res[1]["segments"]] == [s["tokens"] for s in res[4]["segments"]]
+    assert res[4]["segments"][-1]["end"] == pytest.approx(30 * 39 + 7)
