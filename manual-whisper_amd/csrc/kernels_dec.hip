@@ -1198,7 +1198,10 @@ void prepare_mt() {
 template <int MT, bool W8>
 bool launch_gemv_mt(const GemvParams& p, hipStream_t s) {
     const int nks = p.K / (W8 ? 64 : 32);
-    if (p.ln_g) {                   // fused LayerNorm: K = d_model, 512 threads
+    // Many groups: every workgroup of the fused form re-reads and re-normalises its group's fp32 rows (82 KB at
+    // K = 1280), which is what bounds the launch once the weights come from L2; normalise once instead.
+    static const int ln_split_from = getenv("MW_LN_SPLIT_FROM") ? atoi(getenv("MW_LN_SPLIT_FROM")) : 33;
+    if (p.ln_g && p.B < ln_split_from) {                   // fused LayerNorm: K = d_model, 512 threads
         if constexpr (W8) {
             switch (p.K) {
                 case 128: launch_gemv_t<MT, 1, 1, true>(p, 8, s); return true;
@@ -1220,7 +1223,9 @@ bool launch_gemv_mt(const GemvParams& p, hipStream_t s) {
                 default: break;
             }
         }
-        // no fused instantiation for this width: separate LayerNorm launch, then the plain form
+    }
+    if (p.ln_g) {
+        // no fused instantiation for this width (or many groups): separate LayerNorm launch, then the plain form
         launch_layernorm(p.x32, p.ln_g, p.ln_b, p.ln_scratch, nullptr, p.B, p.K, s);
         GemvParams q = p;
         q.ln_g = nullptr; q.ln_b = nullptr; q.xin16 = p.ln_scratch;
