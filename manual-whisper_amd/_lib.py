@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmwhip.so")
+LIB_PATH = os.environ.get("MW_LIB_PATH") or os.path.join(_HERE, "libmwhip.so")      # MW_LIB_PATH: A/B runs of two builds
 
 # every symbol include/mwhip.h declares
 SYMBOLS = (

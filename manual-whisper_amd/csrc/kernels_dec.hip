@@ -84,7 +84,9 @@ __device__ __forceinline__ void group_view(GemvParams& p, int g, int rows_per_gr
 // fp16 form, half as many steps): the fragment is expanded to two fp16 operands in registers and
 // meets the activation columns 16*fg .. 16*fg+7 and 16*fg+8 .. 16*fg+15 of the step.
 template <int MT, int KPW, int XV, int R, bool W8>
-__global__ __launch_bounds__(XV > 0 ? 512 : 1024) void gemv_kernel(GemvParams p) {      // the fused form always runs 512 threads
+// The fused form always runs 512 threads.  With one row tile and up to 16 sequences it fits 128 VGPRs without
+// spilling, which lets two workgroups share a CU (6.7 against 7.1 us for the QKV launch); the larger forms need more.
+__global__ __launch_bounds__(XV > 0 ? 512 : 1024, (XV > 0 && R == 1 && MT == 1) ? 4 : 1) void gemv_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (gridDim.y > 1) group_view(p, blockIdx.y, 16 * MT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
