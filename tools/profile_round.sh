@@ -7,9 +7,9 @@ O=$R/gpurun_out/r1d
 mkdir -p $O
 cd $R
 # kernel stats of the default bench command and of one engine alone
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/e4 -o e4 --output-format csv -- python3 bench.py --no-cpu-baseline > $O/e4.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/e1 -o e1 --output-format csv -- python3 bench.py --no-cpu-baseline --engines 1 --steps 3 --warmup 1 > $O/e1.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/f8 -o f8 --output-format csv -- python3 bench.py --no-cpu-baseline --engines 1 --steps 3 --warmup 1 --weights fp8 --kv fp8 > $O/f8.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/e4 -o e4 --output-format csv -- python3 bench.py --no-cpu-baseline --also-batch 0 > $O/e4.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/e1 -o e1 --output-format csv -- python3 bench.py --no-cpu-baseline --also-batch 0 --engines 1 --steps 3 --warmup 1 > $O/e1.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/f8 -o f8 --output-format csv -- python3 bench.py --no-cpu-baseline --also-batch 0 --engines 1 --steps 3 --warmup 1 --weights fp8 --kv fp8 > $O/f8.log 2>&1
 # counters, fp8 formats, one pass each
 export MW_WEIGHTS=fp8 MW_KV=fp8
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/p_fetch -o p --output-format csv -- python3 tools/pmc_probe.py > $O/p_fetch.log 2>&1
