@@ -1322,7 +1322,11 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
     // narrow outputs: 8 rows per workgroup so that at least ~160 workgroups stream weights
     static const int nv_narrow = getenv("MW_NV_NARROW") ? atoi(getenv("MW_NV_NARROW")) : 8;
     static const int nv_wide = getenv("MW_NV_WIDE") ? atoi(getenv("MW_NV_WIDE")) : 16;
-    p.nv = p.N <= 2048 ? nv_narrow : nv_wide;
+    // several groups (see group_view) already multiply the workgroups: 16 rows each, so that a workgroup's weight
+    // slice is not smaller than the activation rows it has to fetch beside it
+    static const bool grp_nv_off = getenv("MW_GROUP_NV_OFF") != nullptr;
+    const int n_groups = (p.B + 16 * mt - 1) / (16 * mt);
+    p.nv = (p.N <= 2048 && (n_groups < 2 || grp_nv_off)) ? nv_narrow : nv_wide;
     if (p.ln_g && p.nv == 16 && p.N > 256 * 16 && p.N <= 256 * 32)        // at most one workgroup per CU
         p.nv = ((p.N + 255) / 256 + 3) / 4 * 4;
     if (p.out_mode == GV_RESID && !p.ln_g && launch_splitk(p, mt, s)) return;
