@@ -1169,7 +1169,9 @@ void launch_gemv_r(const GemvParams& p, int nw, hipStream_t s) {
 }
 template <int MT, int KPW, int XV, bool W8>
 void launch_gemv_t(const GemvParams& p, int nw, hipStream_t s) {
-    if constexpr (XV > 0) {                 // two row tiles exist for the fused kernels only (the MLP's first matrix)
+    // two row tiles per workgroup: the fused kernels (the MLP's first matrix), and the plain single-tile form when
+    // several groups of sequences share a launch
+    if constexpr (XV > 0 || MT == 1) {
         if (p.nv > 16) { launch_gemv_r<MT, KPW, XV, 2, W8>(p, nw, s); return; }
     }
     launch_gemv_r<MT, KPW, XV, 1, W8>(p, nw, s);
@@ -1231,7 +1233,7 @@ bool launch_gemv_mt(const GemvParams& p, hipStream_t s) {
         launch_layernorm(p.x32, p.ln_g, p.ln_b, p.ln_scratch, nullptr, p.B, p.K, s);
         GemvParams q = p;
         q.ln_g = nullptr; q.ln_b = nullptr; q.xin16 = p.ln_scratch;
-        if (q.nv > 16) q.nv = 16;               // the plain form has one row tile
+        if (q.nv > 16 && MT != 1) q.nv = 16;    // the plain form has two row tiles for MT = 1 only
         return launch_gemv_mt<MT, W8>(q, s);
     }
     const int nw = nks >= 48 ? 16 : nks >= 16 ? 8 : 4;
@@ -1327,6 +1329,8 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
     static const bool grp_nv_off = getenv("MW_GROUP_NV_OFF") != nullptr;
     const int n_groups = (p.B + 16 * mt - 1) / (16 * mt);
     p.nv = (p.N <= 2048 && (n_groups < 2 || grp_nv_off)) ? nv_narrow : nv_wide;
+    static const bool grp_r2 = getenv("MW_GROUP_R2_OFF") == nullptr;      // wide outputs of grouped launches: 32 rows per workgroup
+    if (grp_r2 && n_groups >= 2 && mt == 1 && p.N >= 3072 && p.N % 32 == 0) p.nv = 32;
     if (p.ln_g && p.nv == 16 && p.N > 256 * 16 && p.N <= 256 * 32)        // at most one workgroup per CU
         p.nv = ((p.N + 255) / 256 + 3) / 4 * 4;
     if (p.out_mode == GV_RESID && !p.ln_g && launch_splitk(p, mt, s)) return;

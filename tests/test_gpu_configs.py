@@ -156,3 +156,26 @@ def test_config5_shape_large_v3_batch32():
         assert (la == 12).all() and (a[:16] == lo).all() and (a[16:] == hi).all()
     finally:
         eng.close()
+
+
+def test_large_v3_batch48_runs_as_groups():
+    """48 chunks in one pass at full size (three groups of 16 inside every decode projection launch, LayerNorm as
+    its own launch, two weight-row tiles per workgroup for the wide outputs): every chunk decodes as it does in a
+    batch of 16.  The two routes round differently (fused against separate LayerNorm), so a sequence may part at a
+    near-tie; the first tokens and nearly all sequences must agree."""
+    dims, eng, _ = _engine_and_oracle("large-v3", 48, with_oracle=False)
+    try:
+        opts = synthetic_options(dims, max_new=12, suppress_eot=True)
+        eng.set_decode_options(opts)
+        pcm = synth.make_pcm_np(48, seed=707)
+        a, la = eng.transcribe_batch(pcm)
+        parts = np.concatenate([eng.transcribe_batch(pcm[i:i + 16])[0] for i in (0, 16, 32)])
+        assert (la == 12).all()
+        assert (a[:, :3] == parts[:, :3]).all()
+        assert (a == parts).all(axis=1).sum() >= 45
+        b, _ = eng.transcribe_batch(pcm)
+        assert (a == b).all()                                   # run-to-run identical
+        ragged, _ = eng.transcribe_batch(pcm[:37])
+        assert (ragged == a[:37]).all()                         # group count and a ragged last group do not matter
+    finally:
+        eng.close()
