@@ -89,7 +89,7 @@ typedef struct {
 /* ---- engine life cycle: whisperx.load_model (reference transcribe.py:107-113) ---- */
 
 /* Create an engine on GPU `device` able to process up to `max_batch` (1..128) chunks per call.  Beyond 32
- * sequences the decode projections run as groups of 16 inside each launch: every weight is streamed from HBM
+ * sequences the decode projections run as groups of 32 inside each launch: every weight is streamed from HBM
  * once per step however many groups there are. */
 int mw_create(const mw_model_desc* desc, int device, int max_batch, mw_ctx** out);
 

@@ -49,7 +49,7 @@ __device__ __forceinline__ void e4m3x16_to_f16(const uint4& w, half8& lo, half8&
     hi = half8{h[4][0], h[4][1], h[5][0], h[5][1], h[6][0], h[6][1], h[7][0], h[7][1]};
 }
 
-// Batches beyond one MFMA row tile set (16*MT sequences) run as GROUPS: the same launch carries one copy of
+// Batches beyond one MFMA row tile set (16*MT sequences; MT = 2 by default for such batches) run as GROUPS: the same launch carries one copy of
 // its workgroups per group of 16*MT sequences (grid y, or z for the split-K form), all reading the same weight
 // rows at the same time, so HBM sees the weights once and the other groups hit L2.  A group's workgroups see
 // a parameter block whose row-indexed pointers start at the group's first sequence.
@@ -1310,9 +1310,9 @@ void dec_kernels_prepare() { prepare_mt<1>(); prepare_mt<2>(); }
 
 void launch_gemv(const GemvParams& p0, hipStream_t s) {
     GemvParams p = p0;
-    // up to 16 sequences: one row tile; up to 32: two row tiles per workgroup; beyond: groups of 16 (see group_view)
+    // up to 16 sequences: one row tile; up to 32: two row tiles per workgroup; beyond: groups of 32 (see group_view)
     static const int group_from = getenv("MW_GROUP_FROM") ? atoi(getenv("MW_GROUP_FROM")) : 33;
-    static const int group_mt = getenv("MW_GROUP_MT") ? atoi(getenv("MW_GROUP_MT")) : 1;
+    static const int group_mt = getenv("MW_GROUP_MT") ? atoi(getenv("MW_GROUP_MT")) : 2;
     const int mt = p.B <= 16 ? 1 : p.B < group_from ? 2 : group_mt;
     if (p.out_mode == GV_LOGITS) {
         dim3 grid(gemv_logits_parts(p.N), (p.B + 16 * mt - 1) / (16 * mt));

@@ -103,7 +103,7 @@ struct DecState {          // lives in device memory; one per context
 };
 enum GemvOut { GV_F16 = 0, GV_RESID = 1, GV_QKV = 2, GV_LOGITS = 3 };
 struct GemvParams {
-    int B, N, K;              // B: any number of sequences; more than 32 run as groups of 16 inside the launch
+    int B, N, K;              // B: any number of sequences; more than 32 run as groups of 32 (or 16) inside the launch
     const f16* W;             // [N][K] fp16 ...
     const uint8_t* W8;        // ... or, when non-null, [N][K] OCP e4m3 codes with w_scale [N] (K % 64 == 0); not for GV_LOGITS
     const float* w_scale;
