@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--weights", choices=("f16", "fp8"), default="f16",
                     help="fp8: BASELINE configs[4] (e4m3 Linear weights, fp8 MFMA in the encoder); the default is the metric's configs[2]")
     ap.add_argument("--kv", choices=("f16", "fp8"), default="f16", help="fp8: e4m3 cross-attention K/V cache (needs --weights fp8)")
-    ap.add_argument("--also-batch", type=int, default=64,
+    ap.add_argument("--also-batch", type=int, default=128,
                     help="N=1 only: after the main measurement, the same chunks with this many per engine pass (batches of 16 coalesced "
                          "by the scheduler into one lock-step decode; 0 = skip), reported under 'coalesced'")
     ap.add_argument("--also-engines", type=int, default=3)
