@@ -246,7 +246,8 @@ static int alloc_work(mw_ctx* ctx) {
     ALLOC(ctx->melT, B * (size_t)(kFrames + 2) * d.n_mels, true);
     ALLOC(ctx->h1, B * (size_t)(kFrames + 2) * D, true);
     ALLOC(ctx->x, M * D); ALLOC(ctx->xn, M * D);
-    if (ctx->fp8) { ALLOC(ctx->xn8, M * D); ALLOC(ctx->xs, M); ALLOC(ctx->wexp, D * std::max(D, F)); }
+    // xn8: 256 rows of slack, the fp8 256x256 GEMM reads whole tiles of A without clamping the last one
+    if (ctx->fp8) { ALLOC(ctx->xn8, (M + 256) * D, true); ALLOC(ctx->xs, M); ALLOC(ctx->wexp, D * std::max(D, F)); }
     ALLOC(ctx->q, M * D); ALLOC(ctx->k, M * D);
     ALLOC(ctx->vT, B * H * 64 * (size_t)ctx->Tpad, true);
     ALLOC(ctx->att, M * D); ALLOC(ctx->hid, M * F);

@@ -436,26 +436,54 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int in_group = bid - group * per_group;
     const int m0 = (gm0 + in_group % gsz) * 256, n0 = (in_group / gsz) * 256;
 
-    // per-lane DMA sources: instruction i of a half-tile fills slot rows (wave*2+i)*8 + (lane>>3)
+    // per-lane DMA sources: instruction i of a half-tile fills slot rows (wave*2+i)*8 + (lane>>3).
+    // f16 form: 64-bit pointers through the builtin.  fp8 form: the 8-register MFMA operands leave no room for
+    // eight pointers and their per-issue 64-bit adds (34 registers spilled, and every reload drains the DMA
+    // queue), so it keeps 32-bit byte offsets and issues the load itself with the matrix base + k offset in
+    // scalar registers (both matrices span < 4 GiB: checked by the launcher).
     const f16* a_src[2][2];
     const f16* b_src[2][2];
+    // fp8 form: ONE lane offset per matrix (instruction 0 of half-tile 0).  Half-tile 1 lies a whole number of rows
+    // further (a scalar), instruction 1 eight rows further with the swizzle key's bit 2 flipped (offset ^ 64: the
+    // row pitch is a multiple of 128 bytes, so bits 4..6 of the offset are the chunk alone).  No clamping: the
+    // launcher sends only flat, N % 256 == 0 problems here and A is readable for 255 rows past M.
+    unsigned a_off0b = 0, b_off0b = 0;
+    if constexpr (F8) {
+        const int r = wave * 16 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        a_off0b = (unsigned)(((long)(m0 + (r >> 6) * 128 + (r & 63)) * p.lda + chunk * 8) * 2);
+        b_off0b = (unsigned)(((long)(n0 + (r >> 5) * 64 + (r & 31)) * p.ldw + chunk * 8) * 2);
+    } else {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = (wave * 2 + i) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-            const int m = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
-            a_src[h][i] = p.A + (long)(m / p.a_rows_per_batch) * p.a_batch_stride + (long)(m % p.a_rows_per_batch) * p.lda + chunk * 8;
-            const int n = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
-            b_src[h][i] = p.W + (long)n * p.ldw + chunk * 8;
+            for (int i = 0; i < 2; ++i) {
+                const int r = (wave * 2 + i) * 8 + (lane >> 3);
+                const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+                const int m = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
+                a_src[h][i] = p.A + (long)(m / p.a_rows_per_batch) * p.a_batch_stride + (long)(m % p.a_rows_per_batch) * p.lda + chunk * 8;
+                const int n = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
+                b_src[h][i] = p.W + (long)n * p.ldw + chunk * 8;
+            }
+    }
+    const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) f16*)lds;
+    auto issue = [&](int buf, int slot, bool is_a, int h, int tile) {
+        if constexpr (F8) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(((buf * 4 + slot) * kHalfSlot + wave * 2 * 8 * BK) * 2));
+            const long pitch = (is_a ? p.lda : p.ldw) * 2;                                    // bytes per row
+            const char* sbase = reinterpret_cast<const char*>(is_a ? p.A : p.W) + (long)tile * (BK * 2) + (long)h * (is_a ? 64 : 32) * pitch;
+            const unsigned v0 = is_a ? a_off0b : b_off0b;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(v0), "s"(sbase) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(dst + (unsigned)(8 * BK * 2)), "v"(v0 ^ 64u), "s"(sbase + 8 * pitch) : "memory");
+        } else {
+            const f16* const (&src)[2] = is_a ? a_src[h] : b_src[h];
+            f16* dst = lds + (buf * 4 + slot) * kHalfSlot + wave * 2 * 8 * BK;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)tile * BK),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 8 * BK), 16, 0, 0);
         }
-    auto issue = [&](int buf, int slot, const f16* const (&src)[2], int tile) {
-        f16* dst = lds + (buf * 4 + slot) * kHalfSlot + wave * 2 * 8 * BK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)tile * BK),
-                                             (__attribute__((address_space(3))) void*)(dst + i * 8 * BK), 16, 0, 0);
     };
     // fragment addresses: row r of a slot, 16-byte chunk c -> r*64 + ((c ^ ((r>>1)&7)) << 3); the XOR term
     // depends on fr only (all row offsets are multiples of 16)
@@ -515,30 +543,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     // 2: last K-tile (nothing to issue, the remaining DMA drains 2 -> 0)
     auto ktile = [&](auto bufc, auto modec, int t) {
         constexpr int BUF = decltype(bufc)::value, MODE = decltype(modec)::value;
-        const f16* cur = lds + BUF * 4 * kHalfSlot;
+        // fp8 form: the second buffer lies past the 64 KB reach of a ds_read offset, and left alone the compiler keeps
+        // a second set of lane addresses for it live across the whole loop (spilled, each reload draining the DMA
+        // queue).  An offset it cannot see through is added per K-tile instead.
+        int buf_off = BUF * 4 * kHalfSlot;
+        if constexpr (F8 && BUF == 1) asm volatile("" : "+s"(buf_off));
+        const f16* cur = lds + buf_off;
         // phase 1: quadrant (0,0)
         read_b(cur + SLOT_B0 * kHalfSlot, b0f);
         read_a(cur + SLOT_A0 * kHalfSlot);
-        if constexpr (MODE < 2) issue(BUF ^ 1, SLOT_B1, b_src[1], t + 1);
+        if constexpr (MODE < 2) issue(BUF ^ 1, SLOT_B1, false, 1, t + 1);
         wait_vm<MODE < 2 ? 8 : 2>();
         __builtin_amdgcn_s_barrier();
         quadrant(I0{}, I0{}, b0f);
         __builtin_amdgcn_s_barrier();
         // phase 2: quadrant (0,1)
         read_b(cur + SLOT_B1 * kHalfSlot, b1f);
-        if constexpr (MODE < 2) issue(BUF ^ 1, SLOT_A1, a_src[1], t + 1);
+        if constexpr (MODE < 2) issue(BUF ^ 1, SLOT_A1, true, 1, t + 1);
         wait_vm<MODE < 2 ? 8 : 0>();
         __builtin_amdgcn_s_barrier();
         quadrant(I0{}, I1{}, b1f);
         __builtin_amdgcn_s_barrier();
         // phase 3: quadrant (1,1)
         read_a(cur + SLOT_A1 * kHalfSlot);
-        if constexpr (MODE == 0) issue(BUF, SLOT_A0, a_src[0], t + 2);
+        if constexpr (MODE == 0) issue(BUF, SLOT_A0, true, 0, t + 2);
         __builtin_amdgcn_s_barrier();
         quadrant(I1{}, I1{}, b1f);
         __builtin_amdgcn_s_barrier();
         // phase 4: quadrant (1,0), B0 still in registers
-        if constexpr (MODE == 0) issue(BUF, SLOT_B0, b_src[0], t + 2);
+        if constexpr (MODE == 0) issue(BUF, SLOT_B0, false, 0, t + 2);
         if constexpr (MODE < 2) wait_vm<MODE == 0 ? 8 : 4>();
         __builtin_amdgcn_s_barrier();
         quadrant(I1{}, I0{}, b0f);
@@ -546,9 +579,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     };
 
     const int nk = p.K / BK;                         // even and >= 2 (checked by the launcher)
-    issue(0, SLOT_A0, a_src[0], 0); issue(0, SLOT_B0, b_src[0], 0);
-    issue(0, SLOT_B1, b_src[1], 0); issue(0, SLOT_A1, a_src[1], 0);
-    issue(1, SLOT_A0, a_src[0], 1); issue(1, SLOT_B0, b_src[0], 1);
+    issue(0, SLOT_A0, true, 0, 0); issue(0, SLOT_B0, false, 0, 0);
+    issue(0, SLOT_B1, false, 1, 0); issue(0, SLOT_A1, true, 1, 0);
+    issue(1, SLOT_A0, true, 0, 1); issue(1, SLOT_B0, false, 0, 1);
     wait_vm<8>();                                    // A0, B0 of tile 0 have landed
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();       // second wave row runs one barrier behind
@@ -584,10 +617,10 @@ void launch_gemm(const GemmParams& p0, hipStream_t s) {
         p.K /= 2; p.lda /= 2; p.ldw /= 2; p.a_batch_stride /= 2;
         const int nk = p.K / BK;
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        // The 256x256 form needs 8-register operand tuples on top of the f16 form's 246 VGPRs and spills inside
-        // its K loop (743 against 993 TFLOP/s for the 128x128 form at M=24000, N=3840, K=1280): opt-in only.
-        static const bool use256 = getenv("MW_GEMM_F8_256") != nullptr;
-        if (use256 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256) launch_256<true>(p, s);
+        // 256x256 form: 1200-1290 TFLOP/s at M = 24000..48000, K = 1280 against 1010-1070 for the 128x128 form.
+        static const bool use256 = getenv("MW_GEMM_F8_NO256") == nullptr;
+        const bool flat = p.a_rows_per_batch >= p.M;      // the fp8 256x256 form does not clamp rows (see its DMA offsets)
+        if (use256 && flat && p.N % 256 == 0 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256) launch_256<true>(p, s);
         else launch_t<4, true, true>(p, s);
         return;
     }
