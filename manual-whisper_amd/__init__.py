@@ -7,6 +7,7 @@ HIP library; building an engine does, and fails loudly when the library is missi
 from .dims import WhisperDims, MODELS, get_dims  # noqa: F401
 from .audio import load_audio  # noqa: F401
 from .postprocess import clean_segment_text, remove_hallucination_loops  # noqa: F401
+from .segment_filter import FilterOptions, post_process_segments  # noqa: F401
 from .emit import format_timestamp, format_transcript  # noqa: F401
 
 

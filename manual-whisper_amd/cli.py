@@ -9,6 +9,9 @@ Environment (reference transcribe.py:30-36 plus this engine's own knobs):
   MW_ENGINES     engines in flight on the GPU (default 2)
   MW_COALESCE    batches of BATCH_SIZE chunks joined per engine pass (default 4: passes of up to 64 chunks)
   MW_DTYPE       float16 (default) or float8 (e4m3 Linear weights quantised at load)
+  MW_SEGMENT_FILTER  1: clean up with the web service's rules instead (reference web/api/lib/processor.js:52-113:
+                 filler noise dropped, neighbours merged; the JSON gains cleanup_stats and quality_report as in
+                 web/api/transcribe.js:239)
   HF_TOKEN       accepted for compatibility; diarization is not part of this engine
 Launched under torch.distributed.run, the chunks are sharded over the ranks and rank 0 writes the files.
 """
@@ -19,7 +22,7 @@ import sys
 import time
 from pathlib import Path
 
-from . import emit, postprocess
+from . import emit, postprocess, segment_filter
 from .audio import load_audio
 from .dims import SAMPLE_RATE
 from .model import load_model
@@ -82,6 +85,12 @@ def transcribe_audio(audio_file, hf_token=None):
     say("⚠️ 时间戳对齐与说话人分离不在本引擎范围内：片段时间为语音活动窗口（≤30 秒）的边界。")
     model.close()
     say("🧹 清理转写文本...")
+    if os.environ.get("MW_SEGMENT_FILTER", "0").strip().lower() in ("1", "true", "yes", "on"):
+        done = segment_filter.post_process_segments(result.get("segments", []))
+        result.update(segments=done["segments"], cleanup_stats=done["stats"], quality_report=done["qualityReport"])
+        for line in done["qualityReport"]["warnings"]:
+            say(f"   ⚠️ {line}")
+        return result, audio_duration
     kept, changed, dropped = postprocess.clean_segments(result.get("segments", []))
     result["segments"] = kept
     if changed:
