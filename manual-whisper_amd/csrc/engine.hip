@@ -84,7 +84,8 @@ struct mw_ctx {
     float* xpartial = nullptr; int* xtickets = nullptr;    // cross-attention key-range partials + ticket counters
     float* skpartial = nullptr; int* sktickets = nullptr;  // split-K partial tiles + ticket counters of the residual projections
     // beam search (allocated on first use)
-    float *bm_sum_lp = nullptr, *bm_fin_lp = nullptr;
+    float *bm_sum_lp = nullptr, *bm_fin_lp = nullptr, *bm_part_m = nullptr, *bm_part_s = nullptr, *bm_part_v = nullptr;
+    int* bm_part_i = nullptr;
     int *bm_hist = nullptr, *bm_src_rows = nullptr, *bm_fin_tokens = nullptr, *bm_fin_len = nullptr, *bm_fin_count = nullptr,
         *bm_completed = nullptr;
 
@@ -991,6 +992,8 @@ extern "C" int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience
         ALLOC(ctx->bm_sum_lp, MB); ALLOC(ctx->bm_hist, MB * d.n_text_ctx); ALLOC(ctx->bm_src_rows, MB * d.n_text_ctx);
         ALLOC(ctx->bm_fin_tokens, MB * cand_cap * d.n_text_ctx); ALLOC(ctx->bm_fin_lp, MB * cand_cap);
         ALLOC(ctx->bm_fin_len, MB * cand_cap); ALLOC(ctx->bm_fin_count, MB); ALLOC(ctx->bm_completed, MB);
+        ALLOC(ctx->bm_part_m, MB * kBeamParts); ALLOC(ctx->bm_part_s, MB * kBeamParts);
+        ALLOC(ctx->bm_part_v, MB * kBeamParts * (kMaxBeam + 1)); ALLOC(ctx->bm_part_i, MB * kBeamParts * (kMaxBeam + 1));
     }
     std::vector<int32_t> f((size_t)R * P);
     for (int r = 0; r < R; ++r) memcpy(&f[(size_t)r * P], ctx->prompt.data(), P * 4);
@@ -1006,6 +1009,7 @@ extern "C" int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience
     bp.x = ctx->dx; bp.sum_lp = ctx->bm_sum_lp; bp.hist = ctx->bm_hist; bp.src_rows = ctx->bm_src_rows;
     bp.fin_tokens = ctx->bm_fin_tokens; bp.fin_lp = ctx->bm_fin_lp; bp.fin_len = ctx->bm_fin_len;
     bp.fin_count = ctx->bm_fin_count; bp.completed = ctx->bm_completed;
+    bp.part_m = ctx->bm_part_m; bp.part_s = ctx->bm_part_s; bp.part_v = ctx->bm_part_v; bp.part_i = ctx->bm_part_i;
     hipStream_t s = ctx->stream;
     launch_beam_init(bp, P, max_new, ctx->eot, s);
     HIPCHK(hipGetLastError());

@@ -932,12 +932,72 @@ __global__ __launch_bounds__(256) void beam_init_kernel(BeamParams p, int prompt
     }
 }
 
-__global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
-    constexpr int KMAX = kMaxBeam + 1, NC = kMaxBeam * KMAX;
+// The scan half of a beam step: workgroup (part, sequence) goes over its sixteenth of the sequence's logits under
+// the suppress mask and leaves the running maximum, the sum of exp(v - maximum) and its beam+1 best
+// (logit, id) pairs (descending; ties: lowest id).  beam_step_kernel merges the parts.
+__global__ __launch_bounds__(256) void beam_scan_kernel(BeamParams p) {
+    constexpr int KMAX = kMaxBeam + 1;
     __shared__ float topv[KMAX][256];           // per-thread best-K lists (column = thread)
     __shared__ int topi[KMAX][256];
     __shared__ float wv[4]; __shared__ int wi[4]; __shared__ int wt[4];
     __shared__ float redm[4], reds[4];
+    const int part = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.beam + 1;
+    const int next = p.st->pos, prompt_len = p.st->prompt_len;
+    if (next < prompt_len || p.completed[r / p.beam]) return;
+    const uint8_t* mask = next == prompt_len ? p.mask_first : p.mask_rest;
+    const int per = (p.vocab + kBeamParts - 1) / kBeamParts;
+    const int lo = part * per, hi = min(p.vocab, lo + per);
+    const float* lg = p.logits + (long)r * p.vocab;
+    for (int c = 0; c < K; ++c) { topv[c][tid] = -INFINITY; topi[c][tid] = 0x7fffffff; }
+    float m = -INFINITY, ssum = 0.f;
+    for (int i = lo + tid; i < hi; i += 256) {
+        if (mask[i]) continue;
+        const float v = lg[i];
+        if (v > m) { ssum = ssum * __expf(m - v) + 1.f; m = v; } else { ssum += __expf(v - m); }
+        if (v > topv[K - 1][tid]) {             // indices arrive in increasing order: ties keep the earlier one
+            int c = K - 1;
+            while (c > 0 && v > topv[c - 1][tid]) { topv[c][tid] = topv[c - 1][tid]; topi[c][tid] = topi[c - 1][tid]; --c; }
+            topv[c][tid] = v; topi[c][tid] = i;
+        }
+    }
+    float bm = wave_max(m);
+    if (lane == 0) redm[wave] = bm;
+    __syncthreads();
+    bm = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    const float bs = wave_sum(m == -INFINITY ? 0.f : ssum * __expf(m - bm));
+    if (lane == 0) reds[wave] = bs;
+    __syncthreads();
+    const long slot = (long)r * kBeamParts + part;
+    if (tid == 0) { p.part_m[slot] = bm; p.part_s[slot] = reds[0] + reds[1] + reds[2] + reds[3]; }
+    // K rounds: every thread offers the head of its list; the best (value, then lowest id) is popped
+    int head = 0;
+    for (int c = 0; c < K; ++c) {
+        float v = topv[head < K ? head : K - 1][tid];
+        int ix = topi[head < K ? head : K - 1][tid];
+        if (head >= K) { v = -INFINITY; ix = 0x7fffffff; }
+        int who = tid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(v, o); const int oi = __shfl_xor(ix, o); const int ow = __shfl_xor(who, o);
+            if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; who = ow; }
+        }
+        if (lane == 0) { wv[wave] = v; wi[wave] = ix; wt[wave] = who; }
+        __syncthreads();
+        float gv = wv[0]; int gi = wi[0], gt = wt[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (wv[w] > gv || (wv[w] == gv && wi[w] < gi)) { gv = wv[w]; gi = wi[w]; gt = wt[w]; }
+        if (tid == gt) ++head;
+        if (tid == 0) { p.part_v[slot * KMAX + c] = gv; p.part_i[slot * KMAX + c] = gi; }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
+    constexpr int KMAX = kMaxBeam + 1, NC = kMaxBeam * KMAX;
+    static_assert(kBeamParts * KMAX <= 256, "one thread per (part, rank) candidate");
+    __shared__ float wv[4]; __shared__ int wi[4]; __shared__ int wt[4];
     __shared__ float cand_lp[NC]; __shared__ int cand_tok[NC]; __shared__ int cand_rank[NC];
     __shared__ int new_parent[kMaxBeam], new_tok[kMaxBeam]; __shared__ float new_lp[kMaxBeam];
     __shared__ int fin_parent[NC]; __shared__ float fin_score[NC]; __shared__ int n_fin_new;
@@ -957,39 +1017,23 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
         return;
     }
     const int sample = next - prompt_len;
-    const uint8_t* mask = sample == 0 ? p.mask_first : p.mask_rest;
 
-    // ---- per beam: log-sum-exp over the unmasked vocabulary and the K best tokens
+    // ---- per beam: log-sum-exp over the unmasked vocabulary and the K best tokens, from the scan's parts
     for (int j = 0; j < beam; ++j) {
-        const float* lg = p.logits + (long)(r0 + j) * p.vocab;
-        for (int c = 0; c < K; ++c) { topv[c][tid] = -INFINITY; topi[c][tid] = 0x7fffffff; }
-        float m = -INFINITY, ssum = 0.f;
-        for (int i = tid; i < p.vocab; i += 256) {
-            if (mask[i]) continue;
-            const float v = lg[i];
-            if (v > m) { ssum = ssum * __expf(m - v) + 1.f; m = v; } else { ssum += __expf(v - m); }
-            if (v > topv[K - 1][tid]) {             // indices arrive in increasing order: ties keep the earlier one
-                int c = K - 1;
-                while (c > 0 && v > topv[c - 1][tid]) { topv[c][tid] = topv[c - 1][tid]; topi[c][tid] = topi[c - 1][tid]; --c; }
-                topv[c][tid] = v; topi[c][tid] = i;
-            }
+        const long row = (long)(r0 + j) * kBeamParts;
+        float bm = -INFINITY;
+        for (int q = 0; q < kBeamParts; ++q) bm = fmaxf(bm, p.part_m[row + q]);
+        float bs = 0.f;
+        for (int q = 0; q < kBeamParts; ++q) { const float mq = p.part_m[row + q]; if (mq != -INFINITY) bs += p.part_s[row + q] * __expf(mq - bm); }
+        const float lse = bm + __logf(bs);
+        // thread (part, rank) holds one candidate; K rounds pop the best (value, then lowest id)
+        float mine = -INFINITY; int mine_i = 0x7fffffff;
+        if (tid < kBeamParts * K) {
+            const int q = tid / K, c = tid % K;
+            mine = p.part_v[(row + q) * KMAX + c]; mine_i = p.part_i[(row + q) * KMAX + c];
         }
-        // block log-sum-exp
-        float bm = wave_max(m);
-        if (lane == 0) redm[wave] = bm;
-        __syncthreads();
-        bm = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
-        float bs = wave_sum(m == -INFINITY ? 0.f : ssum * __expf(m - bm));
-        if (lane == 0) reds[wave] = bs;
-        __syncthreads();
-        const float lse = bm + __logf(reds[0] + reds[1] + reds[2] + reds[3]);
-        // K rounds: every thread offers the head of its list; the best (value, then lowest id) is popped
-        int head = 0;
         for (int c = 0; c < K; ++c) {
-            float v = topv[head < K ? head : K - 1][tid];
-            int ix = topi[head < K ? head : K - 1][tid];
-            if (head >= K) { v = -INFINITY; ix = 0x7fffffff; }
-            int who = tid;
+            float v = mine; int ix = mine_i, who = tid;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const float ov = __shfl_xor(v, o); const int oi = __shfl_xor(ix, o); const int ow = __shfl_xor(who, o);
@@ -1001,7 +1045,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
 #pragma unroll
             for (int w = 1; w < 4; ++w)
                 if (wv[w] > gv || (wv[w] == gv && wi[w] < gi)) { gv = wv[w]; gi = wi[w]; gt = wt[w]; }
-            if (tid == gt) ++head;
+            if (tid == gt) { mine = -INFINITY; mine_i = 0x7fffffff; }
             if (tid == 0) {
                 cand_lp[j * K + c] = p.sum_lp[r0 + j] + (gv - lse);
                 cand_tok[j * K + c] = (gi >= 0 && gi < p.vocab) ? gi : eot;
@@ -1414,6 +1458,7 @@ void launch_beam_init(const BeamParams& p, int prompt_len, int max_new, int eot,
 }
 
 void launch_beam_step(const BeamParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(beam_scan_kernel, dim3(kBeamParts, p.n_audio * p.beam), dim3(256), 0, s, p);
     const size_t lds = (size_t)p.beam * p.n_text_ctx * sizeof(int);      // n_text_ctx >= max_new
     hipLaunchKernelGGL(beam_step_kernel, dim3(p.n_audio), dim3(256), lds, s, p);
 }

@@ -198,7 +198,11 @@ struct BeamParams {
     int* fin_tokens;                        // [n_audio][max_cand][max_new]
     float* fin_lp; int* fin_len;            // [n_audio][max_cand]
     int* fin_count; int* completed;         // [n_audio]
+    // per (sequence, vocabulary part) of this step, written by the scan launch and merged by the step launch:
+    float* part_m; float* part_s;           // [n_audio*beam][kBeamParts] running maximum and sum of exp(v - maximum)
+    float* part_v; int* part_i;             // [n_audio*beam][kBeamParts][kMaxBeam + 1] best logits, descending, and their ids
 };
+constexpr int kBeamParts = 16;
 void launch_beam_init(const BeamParams& p, int prompt_len, int max_new, int eot, hipStream_t s);
 void launch_beam_step(const BeamParams& p, hipStream_t s);
 void launch_dec_finalize(const FinalizeParams& p, int B, hipStream_t s);
