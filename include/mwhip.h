@@ -181,7 +181,10 @@ int mw_profile_cross_attention(mw_ctx* ctx, int batch, int iters, float* mean_ms
  * "check_every" (decode steps between host checks for all-finished, default 16),
  * "prefill" (1 = greedy decoding and beam search send all forced prompt positions through the decoder
  * in one pass instead of one step per position, default 1; the reference's initial_prompt, transcribe.py:40,111,
- * makes the prompt several dozen ids long). */
+ * makes the prompt several dozen ids long),
+ * "skip_done" (1 = the decode cross-attention does not read the K/V cache of sequences that have ended, or of
+ * recordings whose beam search is complete: their next token is end-of-text whatever the step computes;
+ * default 1). */
 int mw_set_option(mw_ctx* ctx, const char* key, int value);
 
 int mw_synchronize(mw_ctx* ctx);

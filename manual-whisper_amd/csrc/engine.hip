@@ -32,7 +32,7 @@ struct mw_ctx {
     std::string err;
     std::vector<void*> allocs;
     bool finalized = false;
-    int use_graph = 1, check_every = 16, use_prefill = 1;
+    int use_graph = 1, check_every = 16, use_prefill = 1, skip_done = 1;
     const mw_ctx* parent = nullptr;                       // non-null: weights and tables belong to `parent`
 
     // weights
@@ -341,6 +341,7 @@ extern "C" int mw_fork(mw_ctx* parent, mw_ctx** out) {
     mw_ctx* ctx = new mw_ctx();
     ctx->d = parent->d; ctx->device = parent->device; ctx->max_batch = parent->max_batch;
     ctx->use_graph = parent->use_graph; ctx->check_every = parent->check_every; ctx->use_prefill = parent->use_prefill;
+    ctx->skip_done = parent->skip_done;
     ctx->parent = parent; ctx->finalized = true;
     // shared, read-only on the hot path
     ctx->conv1_w = parent->conv1_w; ctx->conv1_b = parent->conv1_b; ctx->conv2_w = parent->conv2_w; ctx->conv2_b = parent->conv2_b;
@@ -371,6 +372,17 @@ extern "C" int mw_set_option(mw_ctx* ctx, const char* key, int value) {
     if (!strcmp(key, "graph")) ctx->use_graph = value != 0;
     else if (!strcmp(key, "check_every")) ctx->check_every = value < 1 ? 1 : value;
     else if (!strcmp(key, "prefill")) ctx->use_prefill = value != 0;
+    else if (!strcmp(key, "skip_done")) {
+        if (ctx->skip_done != (value != 0)) {           // captured steps carry the old choice
+            HIPCHK(hipSetDevice(ctx->device));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            for (int i = 0; i < kSelfAttnBuckets; ++i) {
+                if (ctx->graph_exec[i]) { (void)hipGraphExecDestroy(ctx->graph_exec[i]); ctx->graph_exec[i] = nullptr; }
+                if (ctx->graph[i]) { (void)hipGraphDestroy(ctx->graph[i]); ctx->graph[i] = nullptr; }
+            }
+        }
+        ctx->skip_done = value != 0;
+    }
     else return fail(ctx, MW_ERR_ARG, std::string("mw_set_option: unknown key ") + key);
     return MW_OK;
 }
@@ -744,17 +756,18 @@ extern "C" int mw_encode(mw_ctx* ctx, const float* mel, int batch, float* enc_ou
 }
 
 // Cross-attention of `rows` query rows over layer li's cached encoder K/V, in whichever format the cache has.
-static void cross_attention(mw_ctx* ctx, int li, const f16* q, f16* out, int rows, int kv_div = 1, int row0 = 0) {
+static void cross_attention(mw_ctx* ctx, int li, const f16* q, f16* out, int rows, int kv_div = 1, int row0 = 0,
+                            const int* done = nullptr, int done_div = 1) {
     const mw_model_desc& d = ctx->d;
     const size_t per_layer = (size_t)ctx->max_batch * d.n_audio_ctx * d.d_model;
     if (ctx->kv8) {
         const size_t per_layer_rows = (size_t)ctx->max_batch * d.n_audio_ctx * d.n_heads;
         launch_dec_cross_attn8(q, ctx->crossK8 + li * per_layer, ctx->crossV8 + li * per_layer, ctx->crossKs + li * per_layer_rows,
                                ctx->crossVs + li * per_layer_rows, out, rows, d.n_heads, d.n_audio_ctx, ctx->xpartial, ctx->xtickets,
-                               ctx->stream, kv_div, row0);
+                               ctx->stream, kv_div, row0, done, done_div);
     } else {
         launch_dec_cross_attn(q, ctx->crossK + li * per_layer, ctx->crossV + li * per_layer, out, rows, d.n_heads, d.n_audio_ctx,
-                              ctx->xpartial, ctx->xtickets, ctx->stream, kv_div, row0);
+                              ctx->xpartial, ctx->xtickets, ctx->stream, kv_div, row0, done, done_div);
     }
 }
 
@@ -810,7 +823,11 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
             p.out_mode = GV_F16; p.out16 = ctx->dq;
             launch_gemv(p, s);
         }
-        cross_attention(ctx, li, ctx->dq, ctx->datt, B, beam ? beam->beam : 1);
+        // sequences that have ended (recordings whose beam search is complete) are skipped: their next token is
+        // end-of-text whatever the step computes
+        // (not when the caller asked for the logits of every position: those are then the model's own throughout)
+        if (beam) cross_attention(ctx, li, ctx->dq, ctx->datt, B, beam->beam, 0, ctx->skip_done ? beam->completed : nullptr, beam->beam);
+        else cross_attention(ctx, li, ctx->dq, ctx->datt, B, 1, 0, (ctx->skip_done && !want_logits) ? fp.finished : nullptr, 1);
         {   GemvParams p = base(D, D, l.co); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
         {   // LN3 + fc1 + GELU
             GemvParams p = base(F, D, l.fc1);

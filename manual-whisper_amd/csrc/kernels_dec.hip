@@ -546,7 +546,8 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
                                                       const f16* __restrict__ vc, f16* __restrict__ out, int H,
                                                       int tstride, int nfixed, const DecState* __restrict__ st,
                                                       float* __restrict__ partial, int* __restrict__ tickets,
-                                                      int kv_div, const int* __restrict__ src_rows, int n_rows) {
+                                                      int kv_div, const int* __restrict__ src_rows, int n_rows,
+                                                      const int* __restrict__ done = nullptr, int done_div = 1) {
     constexpr int NG = NT / 8;            // row groups
     constexpr int NWV = NT / 64;
     __shared__ float part[NWV][64];
@@ -554,6 +555,11 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = S == 1 ? blockIdx.x : blockIdx.x / S;
     const int split = S == 1 ? 0 : blockIdx.x % S;
+    if constexpr (S > 1) {
+        // cross-attention of a sequence that has ended (greedy) or of a recording that has all its hypotheses
+        // (beam search): its token is fixed to end-of-text whatever this launch computes, so its K/V stay unread
+        if (done && done[(bh / H + ((GRP && !IND) ? n_rows : 0)) / done_div]) return;
+    }
     const int ntot = st ? st->pos + 1 : nfixed;
     const int per = (ntot + S - 1) / S;
     const int t0 = split * per;
@@ -709,13 +715,14 @@ __global__ __launch_bounds__(NT, 5) void cross_attn8_kernel(const f16* __restric
                                                          const uint8_t* __restrict__ vc, const float* __restrict__ ks,
                                                          const float* __restrict__ vs, f16* __restrict__ out, int H, int T,
                                                          float* __restrict__ partial, int* __restrict__ tickets, int kv_div,
-                                                         int row0) {
+                                                         int row0, const int* __restrict__ done, int done_div) {
     constexpr int NG = NT / 8;            // row groups
     constexpr int NWV = NT / 64;
     __shared__ float part[NWV][64];
     __shared__ float red[2 * NWV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x / S, split = blockIdx.x % S;
+    if (done && done[(bh / H + (GRP ? row0 : 0)) / done_div]) return;      // ended: see dec_attn_kernel
     const int per = (T + S - 1) / S;
     const int t0 = split * per;
     const int n = min(T, t0 + per) - t0;
@@ -1409,14 +1416,14 @@ void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, 
 }
 
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
-                           int* tickets, hipStream_t s, int kv_div, int row0) {
+                           int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div) {
     // 4 key ranges of 375 frames per (sequence, head); 256 threads = 32 row groups x 12 rows = 384 >= 375
     if (kv_div > 1)
         hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, kc, vc,
-                           out, H, T, T, (const DecState*)nullptr, partial, tickets, kv_div, (const int*)nullptr, row0);
+                           out, H, T, T, (const DecState*)nullptr, partial, tickets, kv_div, (const int*)nullptr, row0, done, done_div);
     else
         hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, kc, vc, out, H,
-                           T, T, (const DecState*)nullptr, partial, tickets, 1, (const int*)nullptr, B);
+                           T, T, (const DecState*)nullptr, partial, tickets, 1, (const int*)nullptr, B, done, done_div);
 }
 
 void launch_prefill_embed(const int* forced, int n_forced, int B, int P, const f16* tok_emb, const f16* pos_emb, float* x, int D,
@@ -1435,14 +1442,14 @@ void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, De
 }
 
 void launch_dec_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
-                            int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div, int row0) {
+                            int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div) {
     // 4 key ranges of 375 frames; 256 threads = 32 row groups x 12 rows = 384 >= 375
     if (kv_div > 1)
         hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, true>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, k8, v8, ks, vs,
-                           out, H, T, partial, tickets, kv_div, row0);
+                           out, H, T, partial, tickets, kv_div, row0, done, done_div);
     else
         hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, false>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, k8, v8, ks, vs,
-                           out, H, T, partial, tickets, 1, 0);
+                           out, H, T, partial, tickets, 1, 0, done, done_div);
 }
 
 void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s) {

@@ -206,6 +206,46 @@ def test_eot_stops_and_pads(micro):
         assert set(ids[b, :lens[b]]) <= {300} and (ids[b, lens[b]:] == eot).all()
 
 
+@pytest.mark.parametrize("formats", [("f16", "f16"), ("fp8", "fp8")])
+@pytest.mark.parametrize("B", [16, 40])
+def test_ended_sequences_are_skipped_without_changing_ids(B, formats):
+    """At the first sampled position only end-of-text and a few other ids are allowed, so part of the batch ends at once
+    and the rest runs on: with the cross-attention of ended sequences skipped (the default) the ids and lengths are
+    those of the full computation, and of the oracle."""
+    from manual_whisper_amd.engine import Engine
+    dims = mw.get_dims("micro")
+    w = synth.make_weights_np(dims, 1234)
+    base = synthetic_options(dims, max_new=10)
+    eng = Engine(dims, 0, B, weight_format=formats[0], kv_format=formats[1])
+    eng.load_weights(w)
+    try:
+        pcm = synth.make_pcm_np(B, seed=77)
+        # the rival of end-of-text at the first position: the id that beats it for closest to half of the sequences
+        eng.set_decode_options(DecodeOptions(base.prompt, base.eot, (), (), 1))
+        eng.logmel(pcm, want_output=False)
+        eng.encode(B, want_output=False)
+        _, _, first = eng.decode_greedy(B, want_logits=True)
+        wins = (first[0] > first[0][:, base.eot:base.eot + 1]).sum(axis=0)
+        rival = int(np.argmin(np.abs(wins - B / 2)))
+        assert 0 < wins[rival] < B
+        keep = {base.eot, rival}
+        opts = DecodeOptions(base.prompt, base.eot, (), tuple(i for i in range(dims.vocab) if i not in keep), 10)
+        eng.set_decode_options(opts)
+        eng.set_option("skip_done", 0)
+        ids0, lens0 = eng.transcribe_batch(pcm)
+        eng.set_option("skip_done", 1)
+        ids1, lens1 = eng.transcribe_batch(pcm)
+        assert (ids0 == ids1).all() and (lens0 == lens1).all()
+        assert (lens1 == 0).any() and (lens1 > 0).any()            # some ended at once, some ran on
+        if formats[0] == "f16":
+            orc = WhisperOracle(dims, w)
+            sel = np.arange(0, B, 5)
+            want, wl = orc.transcribe_ids(pcm[sel], list(opts.prompt), 10, opts.eot, opts.suppress, opts.begin_suppress)
+            assert_ids_match_up_to_ties(ids1[sel], want, orc.last_margins)
+    finally:
+        eng.close()
+
+
 def test_errors_are_reported_not_fatal(micro):
     from manual_whisper_amd.engine import Engine, EngineError
     dims, w, eng = micro
