@@ -6,8 +6,8 @@ Environment (reference transcribe.py:30-36 plus this engine's own knobs):
   BATCH_SIZE     chunks per engine call (default 16 here; the reference's CPU default is 4)
   WHISPER_MODEL  model size / local checkpoint directory / synthetic:<size> (default large-v3)
   MW_MODEL_DIR   where model-size names are looked up
-  MW_ENGINES     engines in flight on the GPU (default 2)
-  MW_COALESCE    batches of BATCH_SIZE chunks joined per engine pass (default 4: passes of up to 64 chunks)
+  MW_ENGINES     engines in flight on the GPU (default 3)
+  MW_COALESCE    batches of BATCH_SIZE chunks joined per engine pass (default 8: passes of up to 128 chunks)
   MW_DTYPE       float16 (default) or float8 (e4m3 Linear weights quantised at load)
   MW_SEGMENT_FILTER  1: clean up with the web service's rules instead (reference web/api/lib/processor.js:52-113:
                  filler noise dropped, neighbours merged; the JSON gains cleanup_stats and quality_report as in
@@ -31,7 +31,7 @@ DEVICE = os.environ.get("MW_DEVICE", "cuda")
 BATCH_SIZE = int(os.environ.get("BATCH_SIZE", "16"))
 COMPUTE_TYPE = os.environ.get("MW_DTYPE", "float16")
 MODEL_SIZE = os.environ.get("WHISPER_MODEL", "large-v3")
-COALESCE = max(1, int(os.environ.get("MW_COALESCE", "4")))
+COALESCE = max(1, int(os.environ.get("MW_COALESCE", "8")))
 HF_TOKEN = os.environ.get("HF_TOKEN")
 
 # reference transcribe.py:39-46
@@ -55,7 +55,7 @@ def transcribe_audio(audio_file, hf_token=None):
     say(f"📝 加载 Whisper {MODEL_SIZE} 模型...")
     model = load_model(MODEL_SIZE, DEVICE, device_index=local_rank, compute_type=COMPUTE_TYPE, language="zh",
                        asr_options={"initial_prompt": INITIAL_PROMPT}, vad_options=VAD_OPTIONS,
-                       max_batch=min(128, max(1, BATCH_SIZE) * COALESCE), n_engines=int(os.environ.get("MW_ENGINES", "2")),
+                       max_batch=min(128, max(1, BATCH_SIZE) * COALESCE), n_engines=int(os.environ.get("MW_ENGINES", "3")),
                        coalesce=COALESCE)
     say(f"   模型加载耗时: {time.time() - t:.1f}s")
     say("🔊 加载音频...")

@@ -142,12 +142,20 @@ class Model:
 
 def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, compute_type: str = "float16",
                asr_options: Optional[dict] = None, language: Optional[str] = None, vad_options: Optional[dict] = None,
-               task: str = "transcribe", max_batch: int = 16, n_engines: int = 1, coalesce: int = 1, **_ignored) -> Model:
+               task: str = "transcribe", max_batch: Optional[int] = None, n_engines: int = 2, coalesce: int = 4,
+               **_ignored) -> Model:
     """Build an engine on GPU ``device_index``.
 
     whisper_arch: a local directory in Hugging Face layout, a model size whose directory is
     ``$MW_MODEL_DIR/<size>``, or ``synthetic:<size>``.
+    The engine's own knobs have defaults a caller of the reference's signature never needs to touch: two engines
+    in flight, batches of ``transcribe(batch_size=...)`` chunks joined four to a pass, passes of up to
+    ``max_batch`` chunks (default 16 * coalesce; at most 128).  large-v3 takes about 0.4 GB of caches and
+    workspaces per chunk of ``max_batch`` and engine.
     """
+    coalesce = max(1, int(coalesce))
+    if max_batch is None:
+        max_batch = min(128, 16 * coalesce)
     if device not in _GPU_NAMES:
         raise EngineError(f"device={device!r}: this engine runs on an MI355X GPU only (use 'cuda'); there is no CPU path")
     if compute_type not in _FP16_NAMES + _FP8_NAMES:
