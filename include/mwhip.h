@@ -178,7 +178,8 @@ int mw_stage_ms(mw_ctx* ctx, float out[5]);
 int mw_profile_cross_attention(mw_ctx* ctx, int batch, int iters, float* mean_ms, double* bytes_per_launch);
 
 /* Engine options: key "graph" (1 = capture the decode step into a hipGraph, default 1),
- * "check_every" (decode steps between host checks for all-finished, default 16),
+ * "check_every" (decode steps between checks for all-finished, default 4; a check is read one check later, so
+ * that the stream never runs dry: a pass ends at most 2 * check_every - 1 steps after its last sequence),
  * "prefill" (1 = greedy decoding and beam search send all forced prompt positions through the decoder
  * in one pass instead of one step per position, default 1; the reference's initial_prompt, transcribe.py:40,111,
  * makes the prompt several dozen ids long),

@@ -32,7 +32,7 @@ struct mw_ctx {
     std::string err;
     std::vector<void*> allocs;
     bool finalized = false;
-    int use_graph = 1, check_every = 16, use_prefill = 1, skip_done = 1;
+    int use_graph = 1, check_every = 4, use_prefill = 1, skip_done = 1;
     const mw_ctx* parent = nullptr;                       // non-null: weights and tables belong to `parent`
 
     // weights
@@ -101,6 +101,8 @@ struct mw_ctx {
 
     // timing
     hipEvent_t ev[6]{};
+    // all-finished polls: the counter is copied into pinned slot (poll & 1) and read one poll later, so the stream never drains
+    int* fin_host = nullptr; hipEvent_t poll_ev[2]{};
     float stage_ms[5]{};
 };
 
@@ -240,6 +242,10 @@ static int alloc_work(mw_ctx* ctx) {
     const size_t D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, B = ctx->max_batch;
     const size_t M = B * T;
     ctx->Tpad = (int)((T + 7) / 8 * 8);
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->fin_host), 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        ctx->err = "hipHostMalloc failed"; return MW_ERR_HIP;
+    }
+    for (auto& e : ctx->poll_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipEventCreate failed"; return MW_ERR_HIP; }
     // encoder workspaces
     ALLOC(ctx->pcm_dev, B * (size_t)kChunkSamples);
     ALLOC(ctx->logmel, B * (size_t)d.n_mels * kFrames);
@@ -329,6 +335,8 @@ extern "C" void mw_destroy(mw_ctx* ctx) {
     for (void* p : ctx->allocs) (void)hipFree(p);
     if (ctx->stage) (void)hipFree(ctx->stage);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->poll_ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->fin_host) (void)hipHostFree(ctx->fin_host);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -893,6 +901,22 @@ static int run_prefill(mw_ctx* ctx, int B, int P, int beam = 1, int* src_rows = 
     return MW_OK;
 }
 
+// Poll number `n` of a decode loop for "all `need` sequences (recordings) have ended": the counter of the steps
+// enqueued so far is copied to a pinned slot, and the slot of the PREVIOUS poll, which the GPU passed
+// check_every steps ago, is what gets waited for and read.  The host therefore stays at most two polls ahead of
+// the GPU and the stream never runs dry, at the price of up to check_every more steps after the last sequence
+// has ended (their rows are padded with end-of-text and their cross-attention is skipped).
+static int poll_finished(mw_ctx* ctx, int n, int need, bool* all_done) {
+    *all_done = false;
+    if (n > 0) {
+        HIPCHK(hipEventSynchronize(ctx->poll_ev[(n - 1) & 1]));
+        if (ctx->fin_host[(n - 1) & 1] >= need) { *all_done = true; return MW_OK; }
+    }
+    HIPCHK(hipMemcpyAsync(&ctx->fin_host[n & 1], &ctx->st->n_finished, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->poll_ev[n & 1], ctx->stream));
+    return MW_OK;
+}
+
 // Capture (or re-use) the graph of one step for this batch size / forced length / logits flag and the
 // self-attention bucket of `n_keys` = position + 1.  Returns the executable graph through `out`.
 static int ensure_graph(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int key, int n_keys, hipGraphExec_t* out,
@@ -922,7 +946,7 @@ static int run_decode(mw_ctx* ctx, int B, int n_forced, int max_new, float* logi
     const int n_steps = max_new > 0 ? n_forced + max_new - 1 : n_forced;
     const bool graph = ctx->use_graph != 0;
     const size_t row = (size_t)B * d.vocab;
-    int host_fin = 0;
+    int n_polls = 0;
     int steps_run = 0;
     int first_step = 0;
     // kv_div == 1 means "own cache" to the cross-attention launcher, so a single-row prompt keeps stepping
@@ -952,9 +976,10 @@ static int run_decode(mw_ctx* ctx, int B, int n_forced, int max_new, float* logi
             }
         }
         if (max_new > 0 && step >= n_forced - 1 && ((step - (n_forced - 1)) % ctx->check_every) == ctx->check_every - 1 && step + 1 < n_steps) {
-            HIPCHK(hipMemcpyAsync(&host_fin, &ctx->st->n_finished, 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            if (host_fin >= B) break;
+            bool all_done = false;
+            int r = poll_finished(ctx, n_polls++, B, &all_done);
+            if (r) return r;
+            if (all_done) break;
         }
     }
     ctx->stage_ms[4] = (float)steps_run;
@@ -1033,7 +1058,7 @@ extern "C" int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience
     FinalizeParams fp = finalize_params(ctx, P);
     const int n_steps = P + max_new - 1;
     const bool graph = ctx->use_graph != 0;
-    int host_fin = 0, steps_run = 0, first_step = 0;
+    int n_polls = 0, steps_run = 0, first_step = 0;
     if (ctx->use_prefill && P >= 2) {                       // the prompt once per recording, in one pass
         int r = run_prefill(ctx, n_audio, P, beam, bp.src_rows);
         if (r) return r;
@@ -1050,9 +1075,10 @@ extern "C" int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience
         } else { enqueue_step(ctx, R, true, fp, step + 1, &bp); HIPCHK(hipGetLastError()); }
         ++steps_run;
         if (step >= P - 1 && ((step - (P - 1)) % ctx->check_every) == ctx->check_every - 1 && step + 1 < n_steps) {
-            HIPCHK(hipMemcpyAsync(&host_fin, &ctx->st->n_finished, 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            if (host_fin >= n_audio) break;
+            bool all_done = false;
+            int r = poll_finished(ctx, n_polls++, n_audio, &all_done);
+            if (r) return r;
+            if (all_done) break;
         }
     }
     ctx->stage_ms[4] = (float)steps_run;
