@@ -115,6 +115,15 @@ class Model:
             self.pool.set_decode_options(self.decode_options(language))
             self._opts_for = language
         chunks, spans = self.windows(audio)
+        # A pass lasts as long as its longest sequence, and a window's token count follows its duration: passes are
+        # filled with windows of like duration (longest first; chunks are independent, so the ids do not change).
+        order = sorted(range(len(spans)), key=lambda i: spans[i][0] - spans[i][1])
+        if order != list(range(len(spans))):
+            got = self.transcribe_ids_chunks(chunks[order], batch_size, language)
+            ids = [None] * len(spans)
+            for rank, i in enumerate(order):
+                ids[i] = got[rank]
+            return spans, ids
         return spans, self.transcribe_ids_chunks(chunks, batch_size, language)
 
     def transcribe_ids_chunks(self, chunks: np.ndarray, batch_size: int = 16, language: Optional[str] = None):
