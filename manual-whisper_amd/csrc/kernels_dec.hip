@@ -553,12 +553,14 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
     __shared__ float part[NWV][64];
     __shared__ float red[2 * NWV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = S == 1 ? blockIdx.x : blockIdx.x / S;
+    // S == 1: grid (sequences * H).  S > 1: grid (H * S, sequences), so that the sequence comes without a division
+    // (same linear workgroup order as a 1-D grid).
+    const int bh = S == 1 ? blockIdx.x : blockIdx.y * H + blockIdx.x / S;
     const int split = S == 1 ? 0 : blockIdx.x % S;
     if constexpr (S > 1) {
         // cross-attention of a sequence that has ended (greedy) or of a recording that has all its hypotheses
         // (beam search): its token is fixed to end-of-text whatever this launch computes, so its K/V stay unread
-        if (done && done[(bh / H + ((GRP && !IND) ? n_rows : 0)) / done_div]) return;
+        if (done && done[(blockIdx.y + ((GRP && !IND) ? n_rows : 0)) / done_div]) return;
     }
     const int ntot = st ? st->pos + 1 : nfixed;
     const int per = (ntot + S - 1) / S;
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
     int seq = 0;
     long bh_kv = bh;
     if constexpr (IND || GRP) {         // compile-time: greedy decoding never reads kv_div (one more scalar-load round trip)
-        seq = bh / H;
+        seq = S == 1 ? bh / H : blockIdx.y;
         // GRP without IND: this launch serves query rows n_rows .. of a longer list (q, out, partial and tickets
         // are local to the launch; kc / vc are not)
         const int seq_all = (GRP && !IND) ? seq + n_rows : seq;
@@ -721,17 +723,16 @@ __global__ __launch_bounds__(NT, 5) void cross_attn8_kernel(const f16* __restric
     __shared__ float part[NWV][64];
     __shared__ float red[2 * NWV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = blockIdx.x / S, split = blockIdx.x % S;
-    if (done && done[(bh / H + (GRP ? row0 : 0)) / done_div]) return;      // ended: see dec_attn_kernel
+    // grid (H * S, sequences): the sequence comes without a division, in the same linear order as a 1-D grid
+    const int seq = blockIdx.y, head = blockIdx.x / S, split = blockIdx.x % S;
+    if (done && done[(seq + (GRP ? row0 : 0)) / done_div]) return;          // ended: see dec_attn_kernel
+    const int bh = seq * H + head;
     const int per = (T + S - 1) / S;
     const int t0 = split * per;
     const int n = min(T, t0 + per) - t0;
     const int rg = tid >> 3, dc = tid & 7;
     long bh_kv = bh;
-    if constexpr (GRP) {
-        const int seq = bh / H;
-        bh_kv = (long)((seq + row0) / kv_div) * H + (bh - seq * H);
-    }
+    if constexpr (GRP) bh_kv = (long)((seq + row0) / kv_div) * H + head;
     const uint8_t* kb = kc + (bh_kv * T + t0) * 64 + dc * 8;
     const uint8_t* vb = vc + (bh_kv * T + t0) * 64 + dc * 8;
     const float* ksb = ks + bh_kv * T + t0;
@@ -1419,10 +1420,10 @@ void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out,
                            int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div) {
     // 4 key ranges of 375 frames per (sequence, head); 256 threads = 32 row groups x 12 rows = 384 >= 375
     if (kv_div > 1)
-        hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, kc, vc,
+        hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true>), dim3(H * kXattnSplit, B), dim3(256), 0, s, q, kc, vc,
                            out, H, T, T, (const DecState*)nullptr, partial, tickets, kv_div, (const int*)nullptr, row0, done, done_div);
     else
-        hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, kc, vc, out, H,
+        hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), dim3(H * kXattnSplit, B), dim3(256), 0, s, q, kc, vc, out, H,
                            T, T, (const DecState*)nullptr, partial, tickets, 1, (const int*)nullptr, B, done, done_div);
 }
 
@@ -1445,10 +1446,10 @@ void launch_dec_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, 
                             int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div) {
     // 4 key ranges of 375 frames; 256 threads = 32 row groups x 12 rows = 384 >= 375
     if (kv_div > 1)
-        hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, true>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, k8, v8, ks, vs,
+        hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, true>), dim3(H * kXattnSplit, B), dim3(256), 0, s, q, k8, v8, ks, vs,
                            out, H, T, partial, tickets, kv_div, row0, done, done_div);
     else
-        hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, false>), dim3(B * H * kXattnSplit), dim3(256), 0, s, q, k8, v8, ks, vs,
+        hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, false>), dim3(H * kXattnSplit, B), dim3(256), 0, s, q, k8, v8, ks, vs,
                            out, H, T, partial, tickets, 1, 0, done, done_div);
 }
 
