@@ -33,6 +33,7 @@ struct mw_ctx {
     std::vector<void*> allocs;
     bool finalized = false;
     int use_graph = 1, check_every = 4, use_prefill = 1, skip_done = 1;
+    bool can_end = true;                    // false when the decode options suppress end-of-text everywhere
     const mw_ctx* parent = nullptr;                       // non-null: weights and tables belong to `parent`
 
     // weights
@@ -359,6 +360,7 @@ extern "C" int mw_fork(mw_ctx* parent, mw_ctx** out) {
     ctx->fp8 = parent->fp8; ctx->kv8 = parent->kv8;
     ctx->basis_cos = parent->basis_cos; ctx->basis_sin = parent->basis_sin; ctx->filt = parent->filt; ctx->n_mels_pad = parent->n_mels_pad;
     ctx->prompt = parent->prompt; ctx->eot = parent->eot; ctx->max_new = parent->max_new; ctx->opts_set = parent->opts_set;
+    ctx->can_end = parent->can_end;
     auto bail = [&](int code) { parent->err = "mw_fork: " + ctx->err; mw_destroy(ctx); return code; };
     if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(MW_ERR_HIP); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(MW_ERR_HIP); }
@@ -373,6 +375,18 @@ extern "C" int mw_fork(mw_ctx* parent, mw_ctx** out) {
     return MW_OK;
 }
 
+// Captured decode steps carry launch arguments that depend on options (whether the cross-attention reads the
+// ended flags): drop them when such an option changes; the next decode captures again.
+static int drop_graphs(mw_ctx* ctx) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < kSelfAttnBuckets; ++i) {
+        if (ctx->graph_exec[i]) { (void)hipGraphExecDestroy(ctx->graph_exec[i]); ctx->graph_exec[i] = nullptr; }
+        if (ctx->graph[i]) { (void)hipGraphDestroy(ctx->graph[i]); ctx->graph[i] = nullptr; }
+    }
+    return MW_OK;
+}
+
 extern "C" const char* mw_last_error(const mw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 extern "C" int mw_set_option(mw_ctx* ctx, const char* key, int value) {
@@ -381,14 +395,7 @@ extern "C" int mw_set_option(mw_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "check_every")) ctx->check_every = value < 1 ? 1 : value;
     else if (!strcmp(key, "prefill")) ctx->use_prefill = value != 0;
     else if (!strcmp(key, "skip_done")) {
-        if (ctx->skip_done != (value != 0)) {           // captured steps carry the old choice
-            HIPCHK(hipSetDevice(ctx->device));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            for (int i = 0; i < kSelfAttnBuckets; ++i) {
-                if (ctx->graph_exec[i]) { (void)hipGraphExecDestroy(ctx->graph_exec[i]); ctx->graph_exec[i] = nullptr; }
-                if (ctx->graph[i]) { (void)hipGraphDestroy(ctx->graph[i]); ctx->graph[i] = nullptr; }
-            }
-        }
+        if (ctx->skip_done != (value != 0)) { int r = drop_graphs(ctx); if (r) return r; }
         ctx->skip_done = value != 0;
     }
     else return fail(ctx, MW_ERR_ARG, std::string("mw_set_option: unknown key ") + key);
@@ -592,6 +599,9 @@ extern "C" int mw_set_decode_opts(mw_ctx* ctx, const mw_decode_opts* o) {
     HIPCHK(hipMemcpy(ctx->mask_first, first.data(), V, hipMemcpyHostToDevice));
     ctx->prompt.assign(o->prompt, o->prompt + o->n_prompt);
     ctx->eot = o->eot; ctx->max_new = o->max_new; ctx->opts_set = true;
+    const bool can_end = rest[o->eot] == 0;     // end-of-text suppressed at every position: no sequence ever ends early
+    if (can_end != ctx->can_end) { int r = drop_graphs(ctx); if (r) return r; }
+    ctx->can_end = can_end;
     return MW_OK;
 }
 
@@ -834,8 +844,8 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
         // sequences that have ended (recordings whose beam search is complete) are skipped: their next token is
         // end-of-text whatever the step computes
         // (not when the caller asked for the logits of every position: those are then the model's own throughout)
-        if (beam) cross_attention(ctx, li, ctx->dq, ctx->datt, B, beam->beam, 0, ctx->skip_done ? beam->completed : nullptr, beam->beam);
-        else cross_attention(ctx, li, ctx->dq, ctx->datt, B, 1, 0, (ctx->skip_done && !want_logits) ? fp.finished : nullptr, 1);
+        if (beam) cross_attention(ctx, li, ctx->dq, ctx->datt, B, beam->beam, 0, (ctx->skip_done && ctx->can_end) ? beam->completed : nullptr, beam->beam);
+        else cross_attention(ctx, li, ctx->dq, ctx->datt, B, 1, 0, (ctx->skip_done && ctx->can_end && !want_logits) ? fp.finished : nullptr, 1);
         {   GemvParams p = base(D, D, l.co); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
         {   // LN3 + fc1 + GELU
             GemvParams p = base(F, D, l.fc1);
