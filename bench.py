@@ -146,6 +146,7 @@ def coalesced_run(args, dims, opts, dev, local_rank):
 
 
 def main():
+    global NEW_TOKENS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -161,7 +162,9 @@ def main():
                          "by the scheduler into one lock-step decode; 0 = skip), reported under 'coalesced'")
     ap.add_argument("--also-engines", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="30 s chunks per step per GPU (configs[4] uses 32)")
+    ap.add_argument("--tokens", type=int, default=NEW_TOKENS, help="sampled tokens per chunk (the metric is quoted at 128; 32 and 224 are the side cases)")
     args = ap.parse_args()
+    NEW_TOKENS = args.tokens
 
     import torch
     import manual_whisper_amd as mw
