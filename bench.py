@@ -38,8 +38,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, spec
 MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X dense fp16 MFMA, spec (no sparsity)
 # HBM bytes per launch of the cross-attention decode kernel at batch 16 from the PMC counters
-# (2 x FETCH_SIZE 60312.6 KB + WRITE_SIZE 530 KB); algorithmic bytes are 122.88 MB.
-XATTN_TRAFFIC_BYTES = 2 * 60312.6 * 1024 + 530.0 * 1024
+# (2 x FETCH_SIZE 60315.8 KB + WRITE_SIZE 530 KB, profiles/round1d_pmc_counters_f16.csv); algorithmic bytes are 122.88 MB.
+XATTN_TRAFFIC_BYTES = 2 * 60315.8 * 1024 + 530.0 * 1024
 # the same for cross_attn8_kernel (e4m3 cache; algorithmic 65.28 MB), profiles/round1d_pmc_counters_fp8_kv8.csv
 XATTN8_TRAFFIC_BYTES = 2 * 32436.7 * 1024 + 530.0 * 1024
 BATCH = 16
@@ -261,7 +261,7 @@ def main():
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (XATTN_TRAFFIC_BYTES if args.kv == "f16" else XATTN8_TRAFFIC_BYTES) if batch == 16 else None,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/"
-                                           + ("round1_hbm_counters.csv" if args.kv == "f16" else "round1d_pmc_counters_fp8_kv8.csv"),
+                                           + ("round1d_pmc_counters_f16.csv" if args.kv == "f16" else "round1d_pmc_counters_fp8_kv8.csv"),
                          "bytes_per_launch": ca_bytes, "avg_launch_us": round(ca_ms * 1e3, 2)},
         }
         # the timed region as a whole (engines overlapped): algorithmic HBM bytes and MFMA flops of all steps over the wall time
