@@ -41,7 +41,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X dense fp16 MFMA, spec (no sparsity)
 # (2 x FETCH_SIZE 60315.8 KB + WRITE_SIZE 530 KB, profiles/round1d_pmc_counters_f16.csv); algorithmic bytes are 122.88 MB.
 XATTN_TRAFFIC_BYTES = 2 * 60315.8 * 1024 + 530.0 * 1024
 # the same for cross_attn8_kernel (e4m3 cache; algorithmic 65.28 MB), profiles/round1d_pmc_counters_fp8_kv8.csv
-XATTN8_TRAFFIC_BYTES = 2 * 32436.7 * 1024 + 530.0 * 1024
+XATTN8_TRAFFIC_BYTES = 2 * 32439.7 * 1024 + 530.0 * 1024
 BATCH = 16
 NEW_TOKENS = 128
 MODEL = "large-v3"
