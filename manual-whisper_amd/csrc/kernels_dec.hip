@@ -541,7 +541,7 @@ constexpr int kPartStride = 68;     // floats per partial: max, sum, 64 outputs,
 // recording r / kv_div (cross-attention: one encoder pass per recording, shared by its beams).  IND:
 // the self-attention cache is never reordered when beams change parents; instead `src_rows`
 // [position][sequence] names the physical cache row that holds each position of a sequence's history.
-template <int NT, int RPT, int S, bool IND = false, bool GRP = false>
+template <int NT, int RPT, int S, bool IND = false, bool GRP = false, bool DONE = false>
 __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ kc,
                                                       const f16* __restrict__ vc, f16* __restrict__ out, int H,
                                                       int tstride, int nfixed, const DecState* __restrict__ st,
@@ -553,14 +553,14 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
     __shared__ float part[NWV][64];
     __shared__ float red[2 * NWV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // S == 1: grid (sequences * H).  S > 1: grid (H * S, sequences), so that the sequence comes without a division
-    // (same linear workgroup order as a 1-D grid).
-    const int bh = S == 1 ? blockIdx.x : blockIdx.y * H + blockIdx.x / S;
+    // Grid (sequences * H * S).  DONE (a form of its own, so that launches without ended flags keep the exact code
+    // they had): grid (H * S, sequences), the same linear workgroup order, and the sequence comes without a division.
+    const int bh = S == 1 ? blockIdx.x : DONE ? blockIdx.y * H + blockIdx.x / S : blockIdx.x / S;
     const int split = S == 1 ? 0 : blockIdx.x % S;
-    if constexpr (S > 1) {
+    if constexpr (DONE) {
         // cross-attention of a sequence that has ended (greedy) or of a recording that has all its hypotheses
         // (beam search): its token is fixed to end-of-text whatever this launch computes, so its K/V stay unread
-        if (done && done[(blockIdx.y + ((GRP && !IND) ? n_rows : 0)) / done_div]) return;
+        if (done[(blockIdx.y + ((GRP && !IND) ? n_rows : 0)) / done_div]) return;
     }
     const int ntot = st ? st->pos + 1 : nfixed;
     const int per = (ntot + S - 1) / S;
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
     int seq = 0;
     long bh_kv = bh;
     if constexpr (IND || GRP) {         // compile-time: greedy decoding never reads kv_div (one more scalar-load round trip)
-        seq = S == 1 ? bh / H : blockIdx.y;
+        seq = DONE ? blockIdx.y : bh / H;
         // GRP without IND: this launch serves query rows n_rows .. of a longer list (q, out, partial and tickets
         // are local to the launch; kc / vc are not)
         const int seq_all = (GRP && !IND) ? seq + n_rows : seq;
@@ -712,7 +712,7 @@ __device__ __forceinline__ void e4m3x8_to_f32(const uint2& w, float (&f)[8]) {
 // (row = group + NG*i), the same number of load instructions as the fp16 form at half the bytes each; the
 // register budget (<= 96) keeps five workgroups per CU, so the 5 * 256 workgroups of a batch-16 launch are all
 // resident at once.
-template <int NT, int RPT, int S, bool GRP>
+template <int NT, int RPT, int S, bool GRP, bool DONE>
 __global__ __launch_bounds__(NT, 5) void cross_attn8_kernel(const f16* __restrict__ q, const uint8_t* __restrict__ kc,
                                                          const uint8_t* __restrict__ vc, const float* __restrict__ ks,
                                                          const float* __restrict__ vs, f16* __restrict__ out, int H, int T,
@@ -723,10 +723,12 @@ __global__ __launch_bounds__(NT, 5) void cross_attn8_kernel(const f16* __restric
     __shared__ float part[NWV][64];
     __shared__ float red[2 * NWV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // grid (H * S, sequences): the sequence comes without a division, in the same linear order as a 1-D grid
-    const int seq = blockIdx.y, head = blockIdx.x / S, split = blockIdx.x % S;
-    if (done && done[(seq + (GRP ? row0 : 0)) / done_div]) return;          // ended: see dec_attn_kernel
-    const int bh = seq * H + head;
+    // DONE: grid (H * S, sequences), the sequence comes without a division; otherwise grid (sequences * H * S)
+    const int split = blockIdx.x % S;
+    const int bh = DONE ? blockIdx.y * H + blockIdx.x / S : blockIdx.x / S;
+    const int seq = DONE ? blockIdx.y : (GRP ? bh / H : 0);
+    const int head = bh - seq * H;          // used by GRP only
+    if constexpr (DONE) { if (done[(seq + (GRP ? row0 : 0)) / done_div]) return; }     // ended: see dec_attn_kernel
     const int per = (T + S - 1) / S;
     const int t0 = split * per;
     const int n = min(T, t0 + per) - t0;
@@ -1419,12 +1421,20 @@ void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, 
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
                            int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div) {
     // 4 key ranges of 375 frames per (sequence, head); 256 threads = 32 row groups x 12 rows = 384 >= 375
-    if (kv_div > 1)
-        hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true>), dim3(H * kXattnSplit, B), dim3(256), 0, s, q, kc, vc,
-                           out, H, T, T, (const DecState*)nullptr, partial, tickets, kv_div, (const int*)nullptr, row0, done, done_div);
-    else
-        hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), dim3(H * kXattnSplit, B), dim3(256), 0, s, q, kc, vc, out, H,
-                           T, T, (const DecState*)nullptr, partial, tickets, 1, (const int*)nullptr, B, done, done_div);
+    const dim3 g1(B * H * kXattnSplit), g2(H * kXattnSplit, B);
+    const DecState* nost = nullptr;
+    const int* norows = nullptr;
+    if (kv_div > 1) {
+        if (done) hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true, true>), g2, dim3(256), 0, s, q, kc, vc, out, H, T, T,
+                                     nost, partial, tickets, kv_div, norows, row0, done, done_div);
+        else hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true>), g1, dim3(256), 0, s, q, kc, vc, out, H, T, T, nost,
+                                partial, tickets, kv_div, norows, row0, done, done_div);
+    } else {
+        if (done) hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, false, true>), g2, dim3(256), 0, s, q, kc, vc, out, H, T, T,
+                                     nost, partial, tickets, 1, norows, B, done, done_div);
+        else hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), g1, dim3(256), 0, s, q, kc, vc, out, H, T, T, nost, partial,
+                                tickets, 1, norows, B, done, done_div);
+    }
 }
 
 void launch_prefill_embed(const int* forced, int n_forced, int B, int P, const f16* tok_emb, const f16* pos_emb, float* x, int D,
@@ -1445,12 +1455,12 @@ void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, De
 void launch_dec_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
                             int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div) {
     // 4 key ranges of 375 frames; 256 threads = 32 row groups x 12 rows = 384 >= 375
-    if (kv_div > 1)
-        hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, true>), dim3(H * kXattnSplit, B), dim3(256), 0, s, q, k8, v8, ks, vs,
-                           out, H, T, partial, tickets, kv_div, row0, done, done_div);
-    else
-        hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, false>), dim3(H * kXattnSplit, B), dim3(256), 0, s, q, k8, v8, ks, vs,
-                           out, H, T, partial, tickets, 1, 0, done, done_div);
+    const dim3 g1(B * H * kXattnSplit), g2(H * kXattnSplit, B);
+#define MW_X8(GRP, DONE, GRID, KVD, R0) hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, GRP, DONE>), GRID, dim3(256), 0, s, q, k8, \
+                                                           v8, ks, vs, out, H, T, partial, tickets, KVD, R0, done, done_div)
+    if (kv_div > 1) { if (done) MW_X8(true, true, g2, kv_div, row0); else MW_X8(true, false, g1, kv_div, row0); }
+    else { if (done) MW_X8(false, true, g2, 1, 0); else MW_X8(false, false, g1, 1, 0); }
+#undef MW_X8
 }
 
 void launch_dec_init(const FinalizeParams& p, int B, int prompt_len, int max_new, int eot, hipStream_t s) {
