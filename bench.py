@@ -107,7 +107,7 @@ def cpu_baseline(dims, weights_np, opts, gpu_ids_fn, weight_format="f16", kv_for
     gpu_ids = gpu_ids_fn(pcm, sample_new)
     threads = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
     return {
-        "value": round(30.0 / t_full, 4), "unit": "audio-seconds/second", "cores": int(threads), "kind": "port",
+        "value": round(30.0 / t_full, 4), "unit": "audio-seconds/second", "cores": int(threads), "host_cpu_count": os.cpu_count(), "kind": "port",
         "sample": (f"numpy fp32 oracle, {MODEL}, 1 chunk of 30 s: log-mel {t1 - t0:.2f}s + encoder {t2 - t1:.2f}s + "
                    f"cross-KV {t_ckv:.2f}s + {steps_sample} decode steps {t_steps:.2f}s measured; decode extrapolated "
                    f"linearly to {steps_full} steps ({NEW_TOKENS} sampled tokens)"),
@@ -129,6 +129,7 @@ def coalesced_run(args, dims, opts, dev, local_rank):
     eng.set_decode_options(opts)
     pool = EnginePool(eng, ne)
     pcms = [synth.make_pcm_torch(nb, seed=5000 + i, device=dev) for i in range(2)]
+    torch.cuda.synchronize()
     for e in pool.engines:
         e.transcribe_batch(pcms[0])
     pool.map([pcms[i % 2] for i in range(ne)])
@@ -145,8 +146,26 @@ def coalesced_run(args, dims, opts, dev, local_rank):
                         f"{steps} passes timed", "ms_per_16_chunks": round(dt / (steps * nb / 16) * 1e3, 3)}
 
 
-def main():
+def free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N fresh rank processes (one per GPU) with
+    torch.distributed.run and pass on their exit code; rank 0's JSON line reaches stdout through the inherited
+    descriptors.  Called before torch or the HIP runtime are imported: this process never touches a GPU."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+
+
+def main(argv=None):
     global NEW_TOKENS
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -163,8 +182,10 @@ def main():
     ap.add_argument("--also-engines", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="30 s chunks per step per GPU (configs[4] uses 32)")
     ap.add_argument("--tokens", type=int, default=NEW_TOKENS, help="sampled tokens per chunk (the metric is quoted at 128; 32 and 224 are the side cases)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     NEW_TOKENS = args.tokens
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, argv))
 
     import torch
     import manual_whisper_amd as mw
@@ -201,6 +222,7 @@ def main():
 
     n_iter = args.warmup + args.steps
     pcms = [synth.make_pcm_torch(batch, seed=1000 * rank + i, device=dev) for i in range(min(n_iter, 4))]
+    torch.cuda.synchronize()                    # the engines read pcm on their own streams: it must be complete
     for e in pool.engines:                      # set-up: every engine captures its decode graph once
         e.transcribe_batch(pcms[0])
 
@@ -250,7 +272,9 @@ def main():
             "rtf": round(elapsed / audio_s, 6),
             "config": {"workload": f"whisper-{args.model} {'fp16' if args.weights == 'f16' else 'fp8 weights'}{' + fp8 cross K/V cache' if args.kv == 'fp8' else ''}, batch={batch}x30 s chunks per GPU, greedy, "
                                    f"{len(opts.prompt)} prompt + {NEW_TOKENS} sampled tokens per chunk (EOT suppressed), "
-                                   f"hipGraph decode step, {args.engines} engines (steps) in flight per GPU",
+                                   f"hipGraph decode step, {args.engines} engines (steps) in flight per GPU, "
+                                   f"GPU_MAX_HW_QUEUES={os.environ['GPU_MAX_HW_QUEUES']} (set by bench.py; the library's own default is HIP's 4)",
+                       "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "parallelism": f"dp{world} over chunks, one all_gather of ids at the end"},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items() if k != "decode_steps"},
             "decode_steps_per_step": int(stage.get("decode_steps", 0)),

@@ -103,3 +103,46 @@ def test_load_model_rejects_what_it_cannot_do():
         mw.load_model("synthetic:micro", "cuda", compute_type="int8")
     with pytest.raises(FileNotFoundError, match="Nothing is downloaded"):
         mw.load_model("large-v3", "cuda")
+
+
+def test_bench_starts_its_own_ranks_before_touching_torch(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it must hand over to torch.distributed.run from a process
+    that has imported neither torch nor the HIP library."""
+    probe = tmp_path / "probe.py"
+    probe.write_text(
+        "import sys, os\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "os.environ.pop('WORLD_SIZE', None)\n"
+        "import subprocess, bench\n"
+        "seen = {}\n"
+        "def fake_call(cmd, **kw):\n"
+        "    seen['cmd'] = cmd\n"
+        "    seen['torch'] = 'torch' in sys.modules\n"
+        "    seen['lib'] = 'manual_whisper_amd._lib' in sys.modules and sys.modules['manual_whisper_amd._lib']._lib is not None\n"
+        "    return 7\n"
+        "subprocess.call = fake_call\n"
+        "try:\n"
+        "    bench.main(['--gpus', '2', '--steps', '3', '--warmup', '1'])\n"
+        "except SystemExit as e:\n"
+        "    seen['rc'] = e.code\n"
+        "cmd = seen['cmd']\n"
+        "assert seen['rc'] == 7 and not seen['torch'] and not seen['lib'], seen\n"
+        "assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=2' in cmd, cmd\n"
+        "assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-6:] == ['--gpus', '2', '--steps', '3', '--warmup', '1'], cmd\n"
+        "print('launcher ok')\n")
+    r = subprocess.run([sys.executable, str(probe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "launcher ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_with_two_gpus_fails_only_for_want_of_a_gpu():
+    """On a box without GPUs the self-launched ranks must get as far as asking for their device."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the CPU-only container")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert "launch with torch.distributed.run" not in out
+    assert "No HIP GPUs" in out or "no such HIP device" in out or "Found no NVIDIA driver" in out or "CUDA" in out or "HIP" in out, out[-2000:]
