@@ -14,6 +14,10 @@
  *    memory (weights, caches, workspaces, captured graph).
  *  - a data pointer may be a host pointer or a device pointer of the
  *    context's GPU; the library asks the HIP runtime which one it is.
+ *    Device buffers are read and written on the context's own (non-blocking)
+ *    stream, which is not ordered against any stream of the caller: an input
+ *    buffer must be complete before the call, and every call returns only
+ *    after its outputs are complete.
  *  - a context is bound to one GPU and one HIP stream and is not thread-safe;
  *    separate contexts are independent.  Multi-GPU = one process per GPU.
  *  - audio is float32 mono 16 kHz in [-1, 1); a chunk is 480000 samples (30 s).

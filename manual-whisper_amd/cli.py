@@ -67,19 +67,25 @@ def transcribe_audio(audio_file, hf_token=None):
     if world > 1:
         import torch
         import torch.distributed as dist
-        from .parallel import transcribe_sharded
+        from .parallel import broadcast_from_rank0, shard_range, transcribe_sharded
         if not dist.is_initialized():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        chunks, spans = model.windows(audio)
-        ids = transcribe_sharded(lambda c: model.transcribe_ids_chunks(c, BATCH_SIZE, "zh"), chunks, model.max_new,
-                                 device=torch.device("cuda", local_rank))
-        result = {"segments": [{"text": model.detokenize(i), "start": round(a, 3), "end": round(b, 3)}
-                               for (a, b), i in zip(spans, ids)], "language": "zh"}
+        # rank 0 alone searches the recording for speech windows; every rank then cuts and transcribes its own block
+        windows = broadcast_from_rank0(model.window_list(audio) if rank == 0 else None)
+        spans = [(round(float(w["start"]), 3), round(float(w["end"]), 3)) for w in windows]
+
+        def mine(a, b):
+            return model.cut(audio, windows[a:b])[0]
+
+        a0, b0 = shard_range(len(windows), rank, world)
+        durations = [w["end"] - w["start"] for w in windows[a0:b0]]
+        ids = transcribe_sharded(lambda c: model.transcribe_ids_chunks(c, BATCH_SIZE, "zh", durations=durations), mine,
+                                 model.max_new, device=torch.device("cuda", local_rank), n_items=len(windows))
+        result = {"segments": [{"text": model.detokenize(i), "start": a, "end": b} for (a, b), i in zip(spans, ids)],
+                  "language": "zh"}
     else:
         result = model.transcribe(audio, batch_size=BATCH_SIZE, language="zh")
-        for seg in result["segments"]:
-            seg.pop("tokens", None)
     dt = time.time() - t
     say(f"   转写耗时: {dt:.1f}s (实时比: {dt/max(audio_duration, 1e-9):.3f}x, {audio_duration/max(dt, 1e-9):.0f} audio-s/s)")
     say("⚠️ 时间戳对齐与说话人分离不在本引擎范围内：片段时间为语音活动窗口（≤30 秒）的边界。")

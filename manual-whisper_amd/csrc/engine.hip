@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -98,7 +99,7 @@ struct mw_ctx {
     // captured decode step
     // one captured step per self-attention context bucket (the launch geometry of that kernel follows the position)
     hipGraph_t graph[kSelfAttnBuckets] = {}; hipGraphExec_t graph_exec[kSelfAttnBuckets] = {};
-    int graph_batch[kSelfAttnBuckets] = {}; int graph_logits[kSelfAttnBuckets] = {-1, -1, -1, -1};
+    long graph_batch[kSelfAttnBuckets] = {}; int graph_logits[kSelfAttnBuckets] = {-1, -1, -1, -1};
 
     // timing
     hipEvent_t ev[6]{};
@@ -929,7 +930,7 @@ static int poll_finished(mw_ctx* ctx, int n, int need, bool* all_done) {
 
 // Capture (or re-use) the graph of one step for this batch size / forced length / logits flag and the
 // self-attention bucket of `n_keys` = position + 1.  Returns the executable graph through `out`.
-static int ensure_graph(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int key, int n_keys, hipGraphExec_t* out,
+static int ensure_graph(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, long key, int n_keys, hipGraphExec_t* out,
                         const BeamParams* beam = nullptr) {
     const int b = dec_self_attn_bucket(n_keys);
     if (!(ctx->graph_exec[b] && ctx->graph_batch[b] == key && ctx->graph_logits[b] == (int)want_logits)) {
@@ -972,7 +973,7 @@ static int run_decode(mw_ctx* ctx, int B, int n_forced, int max_new, float* logi
     for (int step = first_step; step < n_steps; ++step) {       // step feeds position `step`: step + 1 cached keys
         if (graph) {
             hipGraphExec_t g;
-            int r = ensure_graph(ctx, B, want_logits, fp, B * 1024 + n_forced, step + 1, &g);
+            int r = ensure_graph(ctx, B, want_logits, fp, (long)B * 1024 + n_forced, step + 1, &g);
             if (r) return r;
             HIPCHK(hipGraphLaunch(g, s));
         } else { enqueue_step(ctx, B, want_logits, fp, step + 1); HIPCHK(hipGetLastError()); }
@@ -1079,7 +1080,8 @@ extern "C" int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience
     for (int step = first_step; step < n_steps; ++step) {
         if (graph) {
             hipGraphExec_t g;
-            int r = ensure_graph(ctx, R, true, fp, (beam << 24) + (max_cand << 16) + R * 1024 + P, step + 1, &g, &bp);
+            // rows and prompt length in the low word (R <= 128, P <= 448), beam and candidate count in the high one
+            int r = ensure_graph(ctx, R, true, fp, ((long)(beam * 64 + max_cand) << 32) | (long)(R * 1024 + P), step + 1, &g, &bp);
             if (r) return r;
             HIPCHK(hipGraphLaunch(g, s));
         } else { enqueue_step(ctx, R, true, fp, step + 1, &bp); HIPCHK(hipGetLastError()); }

@@ -30,6 +30,7 @@
 #include "mw_kernels.h"
 
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 
 namespace mw {
@@ -374,11 +375,10 @@ template <int MI, bool GLDS, bool F8 = false>
 void launch_t(const GemmParams& p, hipStream_t s) {
     constexpr int BM = MI * 32;
     constexpr size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(f16);
-    static bool prepared = false;
-    if (!prepared) {      // raise the dynamic-LDS limit once (first use is never inside stream capture: the encoder runs first)
+    static std::once_flag prepared;     // raise the dynamic-LDS limit once, whichever engine thread gets here first
+    std::call_once(prepared, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MI, GLDS, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        prepared = true;
-    }
+    });
     const int nt = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL((gemm_kernel<MI, GLDS, F8>), dim3(nt), dim3(256), lds, s, p);
 }
@@ -598,11 +598,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 template <bool F8>
 void launch_256(const GemmParams& p, hipStream_t s) {
     constexpr size_t lds = (size_t)8 * kHalfSlot * sizeof(f16);     // 128 KiB
-    static bool prepared = false;
-    if (!prepared) {
+    static std::once_flag prepared;
+    std::call_once(prepared, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        prepared = true;
-    }
+    });
     const int nt = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     hipLaunchKernelGGL(gemm256_kernel<F8>, dim3(nt), dim3(512), lds, s, p);
 }
@@ -620,7 +619,9 @@ void launch_gemm(const GemmParams& p0, hipStream_t s) {
         // 256x256 form: 1200-1290 TFLOP/s at M = 24000..48000, K = 1280 against 1010-1070 for the 128x128 form.
         static const bool use256 = getenv("MW_GEMM_F8_NO256") == nullptr;
         const bool flat = p.a_rows_per_batch >= p.M;      // the fp8 256x256 form does not clamp rows (see its DMA offsets)
-        if (use256 && flat && p.N % 256 == 0 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256) launch_256<true>(p, s);
+        // ... and addresses both matrices with 32-bit byte offsets (units here are 2 bytes; A is read up to 255 rows past M)
+        const bool fits32 = ((long)(p.M + 256) * p.lda + p.K) * 2 < (1L << 32) && ((long)p.N * p.ldw + p.K) * 2 < (1L << 32);
+        if (use256 && flat && fits32 && p.N % 256 == 0 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256) launch_256<true>(p, s);
         else launch_t<4, true, true>(p, s);
         return;
     }

@@ -23,9 +23,16 @@ class EngineError(RuntimeError):
 
 
 def _ptr(a) -> C.c_void_p:
-    """Address of a numpy array or a torch tensor (host or device)."""
+    """Address of a numpy array or a torch tensor (host or device).
+
+    The engine reads device buffers on its own stream, which is not ordered against the stream that filled
+    them: a tensor on a GPU is handed over only after the work queued on torch's current stream for that
+    device has finished."""
     if isinstance(a, np.ndarray):
         return C.c_void_p(a.ctypes.data)
+    if getattr(a, "is_cuda", False):
+        import torch
+        torch.cuda.current_stream(a.device).synchronize()
     return C.c_void_p(a.data_ptr())
 
 

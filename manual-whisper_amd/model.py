@@ -18,7 +18,7 @@ Differences that cannot be avoided offline, all stated where they bite:
   * decoding is greedy by default (what the throughput figures are quoted on); ``asr_options={"beam_size": 5}``
     switches to beam search at temperature 0 (whisperx's default beam; no temperature fallback), which runs
     ``max_batch // beam_size`` chunks per pass.  No timestamps; text needs tokenizer.json, otherwise a segment's text is
-    its token ids written as ``<|id|>`` and the ids are also returned under ``"tokens"``.
+    its token ids written as ``<|id|>``; ``transcribe(..., return_tokens=True)`` also returns the ids under ``"tokens"``.
 """
 from __future__ import annotations
 
@@ -29,7 +29,7 @@ from typing import Optional
 import numpy as np
 
 from .decode_options import DecodeOptions, synthetic_options, whisper_options
-from .dims import MODELS, WhisperDims, get_dims
+from .dims import CHUNK_SAMPLES, MODELS, SAMPLE_RATE, WhisperDims, get_dims
 from .engine import Engine, EngineError
 from .scheduler import EnginePool, batches_of, split_chunks
 
@@ -100,49 +100,67 @@ class Model:
     def uses_vad(self) -> bool:
         return bool(self.vad_options) and self.vad_options.get("vad_method", "energy") != "fixed"
 
+    def window_list(self, audio: np.ndarray):
+        """Recording -> [{"start": s, "end": s}, ...]: speech windows of at most 30 s, or fixed 30 s chunks.
+        Small enough to send to other ranks, which cut their own share with ``cut``."""
+        if not self.uses_vad():
+            n = int(np.asarray(audio).reshape(-1).shape[0])
+            return [{"start": a / float(SAMPLE_RATE), "end": min(n, a + CHUNK_SAMPLES) / float(SAMPLE_RATE)}
+                    for a in range(0, n, CHUNK_SAMPLES)]
+        from . import vad
+        return [{"start": w["start"], "end": w["end"]} for w in vad.speech_windows(self.engine, audio, self.vad_options)]
+
+    @staticmethod
+    def cut(audio: np.ndarray, windows):
+        """Windows -> ([n, 480000] zero-padded chunks, [(start_s, end_s)])."""
+        from . import vad
+        return vad.cut_windows(audio, windows)
+
     def windows(self, audio: np.ndarray):
         """Recording -> ([n, 480000] chunks, [(start_s, end_s)]): speech windows, or fixed 30 s chunks."""
-        if not self.uses_vad():
-            return split_chunks(audio)
-        from . import vad
-        return vad.cut_windows(audio, vad.speech_windows(self.engine, audio, self.vad_options))
+        return self.cut(audio, self.window_list(audio))
 
     # -- the hot path -------------------------------------------------------------------
     def transcribe_ids(self, audio: np.ndarray, batch_size: int = 16, language: Optional[str] = None):
         """-> (chunk spans [(start, end)], list of id arrays), no text handling."""
-        language = language or self.language
-        if self._opts_for != language:
-            self.pool.set_decode_options(self.decode_options(language))
-            self._opts_for = language
         chunks, spans = self.windows(audio)
-        # A pass lasts as long as its longest sequence, and a window's token count follows its duration: passes are
-        # filled with windows of like duration (longest first; chunks are independent, so the ids do not change).
-        order = sorted(range(len(spans)), key=lambda i: spans[i][0] - spans[i][1])
-        if order != list(range(len(spans))):
-            got = self.transcribe_ids_chunks(chunks[order], batch_size, language)
-            ids = [None] * len(spans)
-            for rank, i in enumerate(order):
-                ids[i] = got[rank]
-            return spans, ids
-        return spans, self.transcribe_ids_chunks(chunks, batch_size, language)
+        return spans, self.transcribe_ids_chunks(chunks, batch_size, language, durations=[b - a for a, b in spans])
 
-    def transcribe_ids_chunks(self, chunks: np.ndarray, batch_size: int = 16, language: Optional[str] = None):
-        """Already-cut chunks [n, 480000] -> list of id arrays (used by the multi-rank path)."""
+    def transcribe_ids_chunks(self, chunks: np.ndarray, batch_size: int = 16, language: Optional[str] = None, durations=None):
+        """Already-cut chunks [n, 480000] -> list of id arrays, in the order of ``chunks`` (also the multi-rank path).
+
+        ``durations`` (seconds of audio per chunk): a pass lasts as long as its longest sequence, and a window's token
+        count follows its duration, so passes are filled with windows of like duration, longest first (chunks are
+        independent: the ids do not change)."""
         language = language or self.language
         if self._opts_for != language:
             self.pool.set_decode_options(self.decode_options(language))
             self._opts_for = language
+        n = len(chunks)
+        order = list(range(n))
+        if durations is not None:
+            order = sorted(order, key=lambda i: -durations[i])        # stable: equal durations keep their order
+        if order != list(range(n)):
+            chunks = chunks[order]
         bs = max(1, min(int(batch_size) * self.coalesce, self.engine.max_batch // self.beam_size))
-        out = []
-        for ids, lens in self.pool.map([chunks[a:b] for a, b in batches_of(len(chunks), bs)]):
-            out.extend(ids[i, : lens[i]].copy() for i in range(ids.shape[0]))
+        got = []
+        for ids, lens in self.pool.map([chunks[a:b] for a, b in batches_of(n, bs)]):
+            got.extend(ids[i, : lens[i]].copy() for i in range(ids.shape[0]))
+        out = [None] * n
+        for rank, i in enumerate(order):
+            out[i] = got[rank]
         return out
 
-    def transcribe(self, audio: np.ndarray, batch_size: int = 16, language: Optional[str] = None, **_ignored) -> dict:
+    def transcribe(self, audio: np.ndarray, batch_size: int = 16, language: Optional[str] = None, return_tokens: bool = False,
+                   **_ignored) -> dict:
+        """The reference's result dict (transcribe.py:162-176,221-223): segments of {"text", "start", "end"}.
+        ``return_tokens=True`` adds each segment's ids under "tokens" (no counterpart in the reference)."""
         language = language or self.language
         spans, ids = self.transcribe_ids(audio, batch_size, language)
-        segments = [{"text": self.detokenize(t), "start": round(a, 3), "end": round(b, 3), "tokens": [int(i) for i in t]}
-                    for (a, b), t in zip(spans, ids)]
+        segments = [{"text": self.detokenize(t), "start": round(a, 3), "end": round(b, 3)} for (a, b), t in zip(spans, ids)]
+        if return_tokens:
+            for seg, t in zip(segments, ids):
+                seg["tokens"] = [int(i) for i in t]
         return {"segments": segments, "language": language}
 
     def close(self):

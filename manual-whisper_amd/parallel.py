@@ -34,13 +34,30 @@ def unpack_rows(rows: np.ndarray) -> List[np.ndarray]:
     return [r[1:1 + r[0]].copy() for r in rows if r[0] >= 0]
 
 
-def transcribe_sharded(transcribe_chunks: Callable[[np.ndarray], List[np.ndarray]], chunks: np.ndarray, max_new: int,
-                       device=None) -> List[np.ndarray]:
-    """Run ``transcribe_chunks`` on this rank's share of ``chunks`` and gather everyone's ids.
+def broadcast_from_rank0(obj):
+    """Rank 0's (small, picklable) object on every rank: the window list of a recording.  A world of one returns it."""
+    try:
+        import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized()
+    except ImportError:
+        on = False
+    if not on or dist.get_world_size() == 1:
+        return obj
+    box = [obj if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
 
-    Works without torch.distributed initialised (world of one).  ``device``: where the gathered
-    tensor lives (a cuda device for nccl, None/cpu for gloo).
+
+def transcribe_sharded(transcribe_chunks: Callable[[np.ndarray], List[np.ndarray]], chunks, max_new: int,
+                       device=None, n_items: int = None) -> List[np.ndarray]:
+    """Run ``transcribe_chunks`` on this rank's share of the chunks and gather everyone's ids.
+
+    ``chunks``: the array of all chunks, or (with ``n_items``) a callable ``(a, b) -> chunks[a:b]`` so that a rank
+    only ever materialises its own share.  Works without torch.distributed initialised (world of one).
+    ``device``: where the gathered tensor lives (a cuda device for nccl, None/cpu for gloo).
     """
+    take = chunks if callable(chunks) else (lambda a, b: chunks[a:b])
+    n = int(n_items) if n_items is not None else len(chunks)
     try:
         import torch
         import torch.distributed as dist
@@ -48,11 +65,10 @@ def transcribe_sharded(transcribe_chunks: Callable[[np.ndarray], List[np.ndarray
     except ImportError:
         on = False
     if not on:
-        return [np.asarray(t, np.int32) for t in transcribe_chunks(chunks)]
+        return [np.asarray(t, np.int32) for t in transcribe_chunks(take(0, n))] if n else []
     rank, world = dist.get_rank(), dist.get_world_size()
-    n = len(chunks)
     a, b = shard_range(n, rank, world)
-    mine = transcribe_chunks(chunks[a:b]) if b > a else []
+    mine = transcribe_chunks(take(a, b)) if b > a else []
     per = (n + world - 1) // world                       # fixed stride so one all_gather suffices
     rows = torch.from_numpy(pack_rows(mine, max_new, per))
     if device is not None:

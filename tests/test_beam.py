@@ -165,7 +165,7 @@ def test_model_transcribe_with_beam_size():
     model = mw.load_model("synthetic:micro", "cuda", asr_options={"beam_size": 5, "max_new_tokens": 8}, max_batch=12, n_engines=2)
     try:
         audio = synth.make_pcm_np(5, seed=44).reshape(-1)[: 16000 * 140]           # 140 s -> 5 chunks -> passes of 2, 2, 1
-        res = model.transcribe(audio, batch_size=16)
+        res = model.transcribe(audio, batch_size=16, return_tokens=True)
         assert len(res["segments"]) == 5
         chunks, _ = model.windows(audio)
         eng = model.engine

@@ -52,7 +52,7 @@ def test_load_model_from_directory(tmp_path, fmt, dtype):
         assert list(opts.prompt) == [50361] + text_ids + [50258, 50260, 50359, 50363]
         assert opts.eot == 50257 and opts.max_new == 8
         pcm = synth.make_pcm_np(2, seed=5).reshape(-1)[: 16000 * 35]            # 35 s -> two fixed chunks
-        res = model.transcribe(pcm, batch_size=2)
+        res = model.transcribe(pcm, batch_size=2, return_tokens=True)
         assert res["language"] == "zh" and [(s["start"], s["end"]) for s in res["segments"]] == [(0.0, 30.0), (30.0, 35.0)]
         for s in res["segments"]:
             assert s["text"] == model.tokenizer.decode(s["tokens"], skip_special_tokens=True)

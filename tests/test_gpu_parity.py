@@ -473,7 +473,7 @@ def test_model_coalesces_batches_without_changing_ids():
         model = mw.load_model("synthetic:micro", "cuda", asr_options={"max_new_tokens": 8}, max_batch=16 * coalesce,
                               coalesce=coalesce)
         try:
-            res[coalesce] = model.transcribe(audio, batch_size=16)
+            res[coalesce] = model.transcribe(audio, batch_size=16, return_tokens=True)
         finally:
             model.close()
     assert len(res[1]["segments"]) == 40

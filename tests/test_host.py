@@ -68,6 +68,15 @@ def fake(c):      # ids derived from the chunk's content; ragged lengths incl. e
 out = parallel.transcribe_sharded(fake, chunks, max_new=5)
 want = fake(chunks)
 assert len(out) == n and all((a == b).all() for a, b in zip(out, want)), (out, want)
+# the same with every rank cutting only its own share, the window list coming from rank 0
+wins = parallel.broadcast_from_rank0(list(range(n)) if dist.get_rank() == 0 else None)
+assert wins == list(range(n))
+taken = []
+def take(a, b):
+    taken.append((a, b)); return chunks[a:b]
+out = parallel.transcribe_sharded(fake, take, max_new=5, n_items=len(wins))
+assert len(out) == n and all((a == b).all() for a, b in zip(out, want)), (out, want)
+assert taken == ([parallel.shard_range(n, dist.get_rank(), 2)] if parallel.shard_range(n, dist.get_rank(), 2)[1] > parallel.shard_range(n, dist.get_rank(), 2)[0] else [])
 print("rank", dist.get_rank(), "ok")
 dist.destroy_process_group()
 '''

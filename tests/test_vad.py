@@ -123,7 +123,7 @@ def test_transcribe_with_speech_windows():
         audio = np.zeros(40 * sr, np.float32)
         audio[2 * sr: 7 * sr] = burst[0][: 5 * sr]
         audio[24 * sr: 32 * sr] = burst[1]
-        res = model.transcribe(audio, batch_size=4)
+        res = model.transcribe(audio, batch_size=4, return_tokens=True)
         segs = res["segments"]
         assert len(segs) == 2
         assert abs(segs[0]["start"] - 2.0) < 0.2 and abs(segs[0]["end"] - 7.0) < 0.2
@@ -135,6 +135,9 @@ def test_transcribe_with_speech_windows():
             assert s["tokens"] == [int(t) for t in ids[i, : lens[i]]]
         assert model.transcribe(np.zeros(5 * sr, np.float32))["segments"] == []
         model.vad_options = {"vad_method": "fixed"}
-        assert len(model.transcribe(audio, batch_size=4)["segments"]) == 2         # ceil(40 s / 30 s)
+        fixed = model.transcribe(audio, batch_size=4)
+        assert len(fixed["segments"]) == 2         # ceil(40 s / 30 s)
+        # the reference's result shape (transcribe.py:162-176,221-223): nothing but text, start, end
+        assert set(fixed) == {"segments", "language"} and all(set(s) == {"text", "start", "end"} for s in fixed["segments"])
     finally:
         model.close()
