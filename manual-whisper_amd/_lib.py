@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MW_LIB_PATH") or os.path.join(_HERE, "libmwhip.so")  
 # every symbol include/mwhip.h declares
 SYMBOLS = (
     "mw_create", "mw_fork", "mw_set_weight", "mw_finalize", "mw_set_decode_opts", "mw_destroy", "mw_last_error",
-    "mw_logmel", "mw_encode", "mw_decode_greedy", "mw_decode_beam", "mw_decode_forced", "mw_transcribe_batch",
+    "mw_logmel", "mw_logmel_noalloc", "mw_encode", "mw_decode_greedy", "mw_decode_beam", "mw_decode_forced", "mw_transcribe_batch",
     "mw_frame_energy_db", "mw_stage_ms", "mw_profile_cross_attention", "mw_set_option", "mw_synchronize",
 )
 
@@ -81,6 +81,7 @@ def load() -> C.CDLL:
     lib.mw_last_error.argtypes = [vp]
     lib.mw_last_error.restype = C.c_char_p
     lib.mw_logmel.argtypes = [vp, f32p, C.c_int, f32p]
+    lib.mw_logmel_noalloc.argtypes = [vp, f32p, C.c_int, f32p]
     lib.mw_encode.argtypes = [vp, f32p, C.c_int, f32p]
     lib.mw_decode_greedy.argtypes = [vp, C.c_int, vp, vp, f32p]
     lib.mw_decode_beam.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, vp, f32p, vp, vp, f32p]

@@ -19,6 +19,30 @@ using namespace mw;
 
 static thread_local std::string g_create_error;
 
+// Scratch of mw_logmel_noalloc, the one entry point that allocates nothing: the per-block maxima of the
+// log-mel kernel (94 floats per chunk, kNoAllocMaxBatch chunks), which mel_norm_kernel reduces to each chunk's
+// maximum.  Every GPU the library runs on holds its own copy of the array at its own address until the process
+// ends; in host code the array's NAME is only a stand-in for it, so the address on each device is asked for
+// once (mw_create, that device current) and only that pointer is ever handed to a kernel.
+constexpr int kNoAllocMaxBatch = 128;
+constexpr int kMelBlocksPerChunk = (kFrames + 31) / 32;        // 94: the grid of launch_mel_dft
+static __device__ __align__(256) float scratch[kNoAllocMaxBatch * kMelBlocksPerChunk];
+constexpr int kMaxDevices = 64;
+static float* g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mutex;
+
+// `device` must be current.  Returns hipSuccess once the device's address is known.
+static hipError_t resolve_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    float* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_scratch_ptr[device] = ptr;
+    return hipSuccess;
+}
+
 // fp16 weights in `w`; or, in an fp8 engine, OCP e4m3 codes in `w8` with one scale per output row in `ws`
 struct LinearW { f16* w = nullptr; float* b = nullptr; uint8_t* w8 = nullptr; float* ws = nullptr; };
 struct NormW { float* g = nullptr; float* b = nullptr; };
@@ -314,6 +338,9 @@ extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, m
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(MW_ERR_HIP); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(MW_ERR_HIP); }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(MW_ERR_HIP); }
+    if (hipError_t e = resolve_scratch(device); e != hipSuccess) {
+        ctx->err = std::string("hipGetSymbolAddress(scratch) failed: ") + hipGetErrorString(e); return bail(MW_ERR_HIP);
+    }
     int r = alloc_weights(ctx);
     if (r) return bail(r);
     r = alloc_work(ctx);
@@ -641,6 +668,33 @@ extern "C" int mw_logmel(mw_ctx* ctx, const float* pcm, int batch, float* mel_ou
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     if (mel_out)
         HIPCHK(hipMemcpyAsync(mel_out, ctx->logmel, (size_t)batch * ctx->d.n_mels * kFrames * 4, hipMemcpyDefault, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventElapsedTime(&ctx->stage_ms[0], ctx->ev[0], ctx->ev[1]));
+    return MW_OK;
+}
+
+// mw_logmel for callers that cannot allocate: everything on the device, nothing allocated or freed.  The raw
+// log-mel goes straight into the caller's output, which the second launch clamps and scales in place; the
+// per-block maxima between the two launches live in this GPU's `scratch` array.
+extern "C" int mw_logmel_noalloc(mw_ctx* ctx, const float* pcm, int batch, float* mel_out) {
+    if (!ctx) return MW_ERR_ARG;
+    int r = check_batch(ctx, batch, "mw_logmel_noalloc");
+    if (r) return r;
+    if (batch > kNoAllocMaxBatch)
+        return fail(ctx, MW_ERR_ARG, "mw_logmel_noalloc: batch exceeds the static scratch (" + std::to_string(kNoAllocMaxBatch) + " chunks)");
+    if (!pcm || !mel_out) return fail(ctx, MW_ERR_ARG, "mw_logmel_noalloc: pcm and mel_out are required");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!is_device_ptr(pcm) || !is_device_ptr(mel_out))
+        return fail(ctx, MW_ERR_ARG, "mw_logmel_noalloc: pcm and mel_out must be device memory (staging host buffers would allocate)");
+    float* blockmax = g_scratch_ptr[ctx->device];           // resolved by mw_create on this device
+    if (!blockmax) return fail(ctx, MW_ERR_STATE, "mw_logmel_noalloc: the scratch address of this device was never resolved");
+    MelTables t{ctx->basis_cos, ctx->basis_sin, ctx->filt, ctx->d.n_mels, ctx->n_mels_pad};
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    launch_mel_dft(pcm, batch, t, mel_out, blockmax, ctx->stream);           // writes every maximum it later reads: nothing to clear
+    launch_mel_norm(mel_out, blockmax, batch, ctx->d.n_mels, ctx->melT, ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    ctx->mel_batch = batch;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipEventElapsedTime(&ctx->stage_ms[0], ctx->ev[0], ctx->ev[1]));
     return MW_OK;

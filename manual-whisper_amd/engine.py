@@ -150,6 +150,14 @@ class Engine:
         self._check(self._lib.mw_logmel(self._h, _ptr(pcm), B, _ptr(out) if want_output else None), "mw_logmel")
         return out
 
+    def logmel_noalloc(self, pcm, mel_out) -> None:
+        """``logmel`` through the entry point that allocates nothing: ``pcm`` [B, 480000] and ``mel_out``
+        [B, n_mels, 3000] are float32 tensors on this GPU (contiguous); at most 128 chunks."""
+        B = self._pcm_batch(pcm)
+        if tuple(mel_out.shape) != (B, self.dims.n_mels, N_FRAMES) or "float32" not in str(mel_out.dtype):
+            raise EngineError(f"mel_out must be float32 {(B, self.dims.n_mels, N_FRAMES)}")
+        self._check(self._lib.mw_logmel_noalloc(self._h, _ptr(pcm), B, _ptr(mel_out)), "mw_logmel_noalloc")
+
     def frame_energy_db(self, audio, frame: int = 400, hop: int = 160) -> np.ndarray:
         """Frame log-energies (dB) of a whole recording: float32 [n] (numpy, or a tensor on this GPU)
         -> float32 [ceil(n / hop)].  Input of the speech-activity window search (vad.py)."""
