@@ -16,7 +16,8 @@ graph each), one host thread per engine, so up to that many steps are in flight 
 decode step is a chain of short latency-bound launches and leaves most of the chip idle.
 
 Rank 0 prints ONE JSON line.  `roofline` is the decode-time cross-attention kernel (the largest
-HBM stream of a step), timed with HIP events on the engine's stream; `cpu_baseline` is the numpy
+HBM stream of a step), `roofline_gemv` the six weight-streaming projection launches of a decoder layer, both
+timed with HIP events on the engine's stream; `fp8_b32` (N=1) is BASELINE configs[4]'s per-GPU shape; `cpu_baseline` is the numpy
 oracle on this node's host cores on a bounded sample (N=1 only).
 """
 import argparse
@@ -37,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, spec
 MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X dense fp16 MFMA, spec (no sparsity)
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix (v_mfma_f32_32x32x2_f32: 256 FLOP/cycle/CU x 256 CUs x 2.4 GHz)
 # HBM bytes per launch of the cross-attention decode kernel at batch 16 from the PMC counters
 # (2 x FETCH_SIZE 60315.8 KB + WRITE_SIZE 530 KB, profiles/round1d_pmc_counters_f16.csv); algorithmic bytes are 122.88 MB.
 XATTN_TRAFFIC_BYTES = 2 * 60315.8 * 1024 + 530.0 * 1024
@@ -70,7 +72,12 @@ def stage_rooflines(dims, batch, n_prompt, n_new, ms, layer_weight_bytes=2, kv8=
         return {"bound": "mfma", "achieved": round(a, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(a / MFMA_F16_PEAK_TFLOPS, 4)}
 
-    out = {"logmel": hbm(mel_bytes, ms["logmel"]), "encoder": mfma(enc_flop, ms["encoder"]),
+    # log-mel: its bytes are trivial; the kernel is a dense 400 x 402 DFT + mel filter bank on the fp32 MFMA (32x32x2)
+    mel_flop = batch * 3000 * (2.0 * 400 * 402 + 2.0 * 201 * dims.n_mels)
+    mel_tf = mel_flop / (ms["logmel"] * 1e-3) / 1e12
+    logmel = {"bound": "mfma (fp32 matrix)", "achieved": round(mel_tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+              "frac": round(mel_tf / MFMA_F32_PEAK_TFLOPS, 4), "hbm_GBps": hbm(mel_bytes, ms["logmel"])["achieved"]}
+    out = {"logmel": logmel, "encoder": mfma(enc_flop, ms["encoder"]),
            "cross_kv": mfma(ckv_flop, ms["cross_kv"]), "decode": hbm(dec_bytes, ms["decode"])}
     floor_ms = (mel_bytes + dec_bytes) / (HBM_PEAK_GBS * 1e6) + (enc_flop + ckv_flop) / (MFMA_F16_PEAK_TFLOPS * 1e9)
     out["sum_of_stage_floors_ms"] = round(floor_ms, 2)
@@ -116,34 +123,53 @@ def cpu_baseline(dims, weights_np, opts, gpu_ids_fn, weight_format="f16", kv_for
     }
 
 
-def coalesced_run(args, dims, opts, dev, local_rank):
-    """The same workload with the scheduler coalescing several batches of 16 into one engine pass: the decode
-    GEMVs then stream every weight once for all of them (groups of 16 sequences inside each launch)."""
+def side_run(dims, opts, dev, local_rank, batch, engines, weights="f16", kv="f16", rounds=2):
+    """A second measurement on the same GPU after the main one: `rounds * engines` passes of `batch` chunks over
+    `engines` engines in flight; audio-seconds per second and ms per 16 chunks."""
     import torch
     from manual_whisper_amd import synth
     from manual_whisper_amd.engine import Engine
     from manual_whisper_amd.scheduler import EnginePool
-    nb, ne = args.also_batch, args.also_engines
-    eng = Engine(dims, device=local_rank, max_batch=nb, weight_format=args.weights, kv_format=args.kv)
+    eng = Engine(dims, device=local_rank, max_batch=batch, weight_format=weights, kv_format=kv)
     eng.load_weights(synth.make_weights_torch(dims, seed=1234, device=dev))
     eng.set_decode_options(opts)
-    pool = EnginePool(eng, ne)
-    pcms = [synth.make_pcm_torch(nb, seed=5000 + i, device=dev) for i in range(2)]
+    pool = EnginePool(eng, engines)
+    pcms = [synth.make_pcm_torch(batch, seed=5000 + i, device=dev) for i in range(2)]
     torch.cuda.synchronize()
     for e in pool.engines:
         e.transcribe_batch(pcms[0])
-    pool.map([pcms[i % 2] for i in range(ne)])
+    pool.map([pcms[i % 2] for i in range(engines)])
     torch.cuda.synchronize()
-    steps = 2 * ne
+    steps = rounds * engines
     t0 = time.perf_counter()
     pool.map([pcms[i % 2] for i in range(steps)])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pool.close()
     torch.cuda.empty_cache()
-    return {"value": round(steps * nb * 30.0 / dt, 2), "unit": "audio-seconds/second",
-            "workload": f"as config.workload, but {nb} chunks ({nb // 16} batches of 16) per engine pass, {ne} engines in flight, "
-                        f"{steps} passes timed", "ms_per_16_chunks": round(dt / (steps * nb / 16) * 1e3, 3)}
+    return {"value": round(steps * batch * 30.0 / dt, 2), "unit": "audio-seconds/second", "passes_timed": steps,
+            "ms_per_16_chunks": round(dt / (steps * batch / 16) * 1e3, 3)}
+
+
+def coalesced_run(args, dims, opts, dev, local_rank):
+    """The same workload with the scheduler coalescing several batches of 16 into one engine pass: the decode
+    GEMVs then stream every weight once for all of them (groups of 16 sequences inside each launch)."""
+    nb, ne = args.also_batch, args.also_engines
+    out = side_run(dims, opts, dev, local_rank, nb, ne, args.weights, args.kv)
+    out["workload"] = (f"as config.workload, but {nb} chunks ({nb // 16} batches of 16) per engine pass, {ne} engines in flight, "
+                       f"{out['passes_timed']} passes timed")
+    return out
+
+
+def fp8_b32_run(dims, opts, dev, local_rank):
+    """BASELINE configs[4]'s per-GPU shape beside the fp16 headline: e4m3 Linear weights, 32 chunks per pass.
+    The e4m3 cross-attention K/V cache is this build's own extension, not part of configs[4]: reported apart."""
+    out = {"workload": "whisper-large-v3, fp8 (e4m3) Linear weights with fp8 MFMA in the encoder, batch=32x30 s chunks per pass, greedy, "
+                       f"{len(opts.prompt)} prompt + {opts.max_new} sampled tokens per chunk (EOT suppressed), 3 engines in flight, 1 GPU",
+           "fp8_weights": side_run(dims, opts, dev, local_rank, 32, 3, "fp8", "f16"),
+           "fp8_weights_and_fp8_cross_kv_cache": side_run(dims, opts, dev, local_rank, 32, 3, "fp8", "fp8")}
+    out["fp8_weights_and_fp8_cross_kv_cache"]["note"] = "the e4m3 cross K/V cache is an extension of this build, outside configs[4]"
+    return out
 
 
 def free_port() -> int:
@@ -171,15 +197,22 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default=MODEL)
-    ap.add_argument("--engines", type=int, default=4, help="engines in flight per GPU (1 = strictly sequential steps)")
+    ap.add_argument("--engines", type=int, default=4, help="with --group 1: engines in flight per GPU, each running whole passes (1 = strictly sequential steps)")
+    ap.add_argument("--group", type=int, default=7,
+                    help="steps (batches) decoded together: the encoder half of every step runs on its own 16 chunks, the greedy loop over "
+                         "up to this many steps' sequences at once (scheduler.GroupedPool); 1 = every engine runs whole passes")
+    ap.add_argument("--encoders", type=int, default=2, help="with --group > 1: engines running encoder halves")
+    ap.add_argument("--decoders", type=int, default=3, help="with --group > 1: engines running decode groups")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--weights", choices=("f16", "fp8"), default="f16",
                     help="fp8: BASELINE configs[4] (e4m3 Linear weights, fp8 MFMA in the encoder); the default is the metric's configs[2]")
     ap.add_argument("--kv", choices=("f16", "fp8"), default="f16", help="fp8: e4m3 cross-attention K/V cache (needs --weights fp8)")
-    ap.add_argument("--also-batch", type=int, default=128,
+    ap.add_argument("--also-batch", type=int, default=0,
                     help="N=1 only: after the main measurement, the same chunks with this many per engine pass (batches of 16 coalesced "
                          "by the scheduler into one lock-step decode; 0 = skip), reported under 'coalesced'")
     ap.add_argument("--also-engines", type=int, default=3)
+    ap.add_argument("--no-ungrouped", action="store_true", help="N=1 only: skip the side measurement with --group 1 --engines 4")
+    ap.add_argument("--no-fp8-b32", action="store_true", help="N=1 only: skip the configs[4] side measurement (fp8 weights, batch 32)")
     ap.add_argument("--batch", type=int, default=16, help="30 s chunks per step per GPU (configs[4] uses 32)")
     ap.add_argument("--tokens", type=int, default=NEW_TOKENS, help="sampled tokens per chunk (the metric is quoted at 128; 32 and 224 are the side cases)")
     args = ap.parse_args(argv)
@@ -192,7 +225,7 @@ def main(argv=None):
     from manual_whisper_amd import synth
     from manual_whisper_amd.decode_options import synthetic_options
     from manual_whisper_amd.engine import Engine
-    from manual_whisper_amd.scheduler import EnginePool
+    from manual_whisper_amd.scheduler import EnginePool, GroupedPool
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -213,7 +246,10 @@ def main(argv=None):
     eng = Engine(dims, device=local_rank, max_batch=batch, weight_format=args.weights, kv_format=args.kv)
     eng.load_weights(weights)
     eng.set_decode_options(opts)
-    pool = EnginePool(eng, args.engines)
+    grouped = args.group > 1
+    pool = GroupedPool(eng, batch, args.group, args.encoders, args.decoders) if grouped else EnginePool(eng, args.engines)
+    if grouped:
+        pool.set_decode_options(opts)
     weights_np = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         weights_np = {k: v.float().cpu().numpy() for k, v in weights.items()}
@@ -223,8 +259,11 @@ def main(argv=None):
     n_iter = args.warmup + args.steps
     pcms = [synth.make_pcm_torch(batch, seed=1000 * rank + i, device=dev) for i in range(min(n_iter, 4))]
     torch.cuda.synchronize()                    # the engines read pcm on their own streams: it must be complete
-    for e in pool.engines:                      # set-up: every engine captures its decode graph once
-        e.transcribe_batch(pcms[0])
+    if grouped:                                 # set-up: every decode engine captures its graphs once, every encoder runs once
+        pool.map([pcms[0]] * (args.group * args.decoders))
+    else:
+        for e in pool.engines:                  # set-up: every engine captures its decode graph once
+            e.transcribe_batch(pcms[0])
 
     def fence():
         torch.cuda.synchronize()
@@ -248,9 +287,15 @@ def main(argv=None):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     stage = {}
-    for e in pool.engines:                      # last step of each engine; engines overlap, so these do not add up to the wall time
-        for k, v in e.stage_ms().items():
-            stage[k] = stage.get(k, 0.0) + v / len(pool.engines)
+    if grouped:                                 # last call of each engine (encoders: one step's encoder half; decoders: one group's loop)
+        for k in ("logmel", "encoder", "cross_kv"):
+            stage[k] = sum(e.stage_ms()[k] for e in pool.encoders) / len(pool.encoders)
+        stage["decode"] = sum(e.stage_ms()["decode"] for e in pool.decoders) / len(pool.decoders)
+        stage["decode_steps"] = pool.decoders[0].stage_ms()["decode_steps"]
+    else:
+        for e in pool.engines:                  # last step of each engine; engines overlap, so these do not add up to the wall time
+            for k, v in e.stage_ms().items():
+                stage[k] = stage.get(k, 0.0) + v / len(pool.engines)
 
     eng.transcribe_batch(pcms[0])               # one step with the GPU to itself: per-stage rooflines
     solo_ms = eng.stage_ms()
@@ -258,6 +303,9 @@ def main(argv=None):
     # dominant kernel: decode-time cross-attention, HIP events on the engine's own stream
     ca_ms, ca_bytes = eng.profile_cross_attention(batch, iters=256)
     achieved = ca_bytes / (ca_ms * 1e-3) / 1e9
+    # the six weight-streaming projections of a decoder layer, back to back as in a step (launch boundaries included)
+    gv_ms, gv_bytes = eng.profile_decode_gemvs(batch, iters=256)
+    gv_achieved = gv_bytes / (gv_ms * 1e-3) / 1e9
 
     if rank == 0:
         audio_s = world * batch * 30.0 * args.steps
@@ -272,7 +320,9 @@ def main(argv=None):
             "rtf": round(elapsed / audio_s, 6),
             "config": {"workload": f"whisper-{args.model} {'fp16' if args.weights == 'f16' else 'fp8 weights'}{' + fp8 cross K/V cache' if args.kv == 'fp8' else ''}, batch={batch}x30 s chunks per GPU, greedy, "
                                    f"{len(opts.prompt)} prompt + {NEW_TOKENS} sampled tokens per chunk (EOT suppressed), "
-                                   f"hipGraph decode step, {args.engines} engines (steps) in flight per GPU, "
+                                   f"hipGraph decode step, " + (f"every step's log-mel / encoder / cross-K/V on its own 16 chunks ({args.encoders} encoder engines), "
+                                                                f"greedy loop over the sequences of up to {args.group} steps at once ({args.decoders} decode engines), "
+                                                                if grouped else f"{args.engines} engines (steps) in flight per GPU, ") +
                                    f"GPU_MAX_HW_QUEUES={os.environ['GPU_MAX_HW_QUEUES']} (set by bench.py; the library's own default is HIP's 4)",
                        "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "parallelism": f"dp{world} over chunks, one all_gather of ids at the end"},
@@ -288,6 +338,10 @@ def main(argv=None):
                                            + ("round1d_pmc_counters_f16.csv" if args.kv == "f16" else "round1d_pmc_counters_fp8_kv8.csv"),
                          "bytes_per_launch": ca_bytes, "avg_launch_us": round(ca_ms * 1e3, 2)},
         }
+        out["roofline_gemv"] = {
+            "kernels": "the six projection launches of a decoder layer (gemv_kernel x5, gemv_splitk_kernel), one token, back to back",
+            "bound": "hbm", "achieved": round(gv_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gv_achieved / HBM_PEAK_GBS, 4),
+            "bytes_per_layer": gv_bytes, "avg_layer_us": round(gv_ms * 1e3, 2), "traffic": None}
         # the timed region as a whole (engines overlapped): algorithmic HBM bytes and MFMA flops of all steps over the wall time
         sr = out["stage_roofline"]
         hb = sr["algorithmic_hbm_bytes_per_step"] * world * args.steps / elapsed / 1e9
@@ -295,8 +349,15 @@ def main(argv=None):
         out["whole_run"] = {"hbm_GBps_per_gpu": round(hb / world, 1), "hbm_frac": round(hb / world / HBM_PEAK_GBS, 4),
                             "mfma_TFLOPs_per_gpu": round(fl / world, 1), "mfma_frac": round(fl / world / MFMA_F16_PEAK_TFLOPS, 4),
                             "step_floor_over_step": round(sr["sum_of_stage_floors_ms"] / (elapsed / args.steps * 1e3), 4)}
+        if grouped:
+            out["stage_ms_note"] = "decode: one group's loop (all its steps' sequences); the other stages: one step's 16 chunks"
         if world == 1 and args.also_batch > batch:
             out["coalesced"] = coalesced_run(args, dims, opts, dev, local_rank)
+        if world == 1 and grouped and not args.no_ungrouped:
+            out["ungrouped"] = side_run(dims, opts, dev, local_rank, batch, 4, args.weights, args.kv)
+            out["ungrouped"]["workload"] = "as config.workload, but 4 engines in flight that each run whole passes of 16 chunks (decode per step)"
+        if world == 1 and not args.no_fp8_b32 and args.model == MODEL and args.weights == "f16":
+            out["fp8_b32"] = fp8_b32_run(dims, opts, dev, local_rank)
         if weights_np is not None:
             def gpu_ids(pcm, n_new):
                 o = synthetic_options(dims, max_new=n_new, suppress_eot=True)

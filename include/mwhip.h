@@ -115,6 +115,11 @@ int mw_set_decode_opts(mw_ctx* ctx, const mw_decode_opts* opts);
  * Destroy every fork before its parent.  No counterpart in the reference (single engine). */
 int mw_fork(mw_ctx* parent, mw_ctx** out);
 
+/* mw_fork with a max_batch of its own (1..128): workspaces and caches are sized per context, so a set of
+ * contexts can split roles, e.g. forks of 16 that run the encoder half of passes and forks of 64 that decode
+ * what they encoded (mw_encode_into). */
+int mw_fork_sized(mw_ctx* parent, int max_batch, mw_ctx** out);
+
 /* Free everything the context owns (reference transcribe.py:153-154 `del model`). */
 void mw_destroy(mw_ctx* ctx);
 
@@ -143,6 +148,20 @@ int mw_logmel_noalloc(mw_ctx* ctx, const float* pcm, int batch, float* mel_out);
  * mel (optional): float32 [batch][n_mels][3000] to use instead of the features left by
  * mw_logmel. enc_out (optional): float32 [batch][n_audio_ctx][d_model]. */
 int mw_encode(mw_ctx* ctx, const float* mel, int batch, float* enc_out);
+
+/* Stages 1 and 2 of `batch` chunks on `ctx` (its stream and workspaces; pcm float32 [batch][480000]), with the
+ * decoder's cross-attention K/V written into the cache of `dst` at sequences slot0 .. slot0 + batch - 1.
+ * `dst` is `ctx` itself, its parent or another fork of that parent; slot0 + batch <= dst's max_batch.  The
+ * call returns when the K/V are complete.  Several contexts may fill disjoint slots of one destination at the
+ * same time (each from its own thread); the destination must not be decoding meanwhile.  With this the chunks
+ * of model.transcribe (reference transcribe.py:123, batch_size chunks per encoder pass) can be decoded in
+ * larger groups than they were encoded in: every decoder weight is streamed once per step for the whole group.
+ * No counterpart in the reference. */
+int mw_encode_into(mw_ctx* ctx, const float* pcm, int batch, mw_ctx* dst, int slot0);
+
+/* Declare sequences 0 .. batch - 1 of the context's cross-attention cache encoded (by mw_encode_into calls that
+ * have returned): mw_decode_greedy / mw_decode_beam / mw_decode_forced of `batch` sequences may follow. */
+int mw_set_encoded(mw_ctx* ctx, int batch);
 
 /* Stage 3: greedy decoding of the chunks encoded last.
  * out_ids: int32 [batch][max_new] (padded with eot); out_len: int32 [batch] = tokens
@@ -191,6 +210,13 @@ int mw_stage_ms(mw_ctx* ctx, float out[5]);
  * caches (cycling through the layers) and report its mean duration (ms, HIP events on the
  * context's stream) and the K/V bytes one launch must read. */
 int mw_profile_cross_attention(mw_ctx* ctx, int batch, int iters, float* mean_ms, double* bytes_per_launch);
+
+/* Re-run only the six weight-streaming projections of a decoder layer (QKV, attention out, cross-attention query
+ * and out, MLP in and out; the launches of a real step without the two attention launches between them) for
+ * `iters` layers back to back, cycling through the model's layers, and report the mean time per layer (ms, HIP
+ * events on the context's stream, launch boundaries included) and the weight bytes of a layer's six matrices.
+ * Leaves the decode state at position 0 of a fresh decode. */
+int mw_profile_decode_gemvs(mw_ctx* ctx, int batch, int iters, float* mean_ms_per_layer, double* weight_bytes_per_layer);
 
 /* Engine options: key "graph" (1 = capture the decode step into a hipGraph, default 1),
  * "check_every" (decode steps between checks for all-finished, default 4; a check is read one check later, so

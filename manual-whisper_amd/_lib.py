@@ -13,9 +13,9 @@ LIB_PATH = os.environ.get("MW_LIB_PATH") or os.path.join(_HERE, "libmwhip.so")  
 
 # every symbol include/mwhip.h declares
 SYMBOLS = (
-    "mw_create", "mw_fork", "mw_set_weight", "mw_finalize", "mw_set_decode_opts", "mw_destroy", "mw_last_error",
-    "mw_logmel", "mw_logmel_noalloc", "mw_encode", "mw_decode_greedy", "mw_decode_beam", "mw_decode_forced", "mw_transcribe_batch",
-    "mw_frame_energy_db", "mw_stage_ms", "mw_profile_cross_attention", "mw_set_option", "mw_synchronize",
+    "mw_create", "mw_fork", "mw_fork_sized", "mw_set_weight", "mw_finalize", "mw_set_decode_opts", "mw_destroy", "mw_last_error",
+    "mw_logmel", "mw_logmel_noalloc", "mw_encode", "mw_encode_into", "mw_set_encoded", "mw_decode_greedy", "mw_decode_beam", "mw_decode_forced", "mw_transcribe_batch",
+    "mw_frame_energy_db", "mw_stage_ms", "mw_profile_cross_attention", "mw_profile_decode_gemvs", "mw_set_option", "mw_synchronize",
 )
 
 
@@ -73,6 +73,9 @@ def load() -> C.CDLL:
     vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p
     lib.mw_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.c_int, C.POINTER(vp)]
     lib.mw_fork.argtypes = [vp, C.POINTER(vp)]
+    lib.mw_fork_sized.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    lib.mw_encode_into.argtypes = [vp, f32p, C.c_int, vp, C.c_int]
+    lib.mw_set_encoded.argtypes = [vp, C.c_int]
     lib.mw_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int, C.c_int]
     lib.mw_finalize.argtypes = [vp]
     lib.mw_set_decode_opts.argtypes = [vp, C.POINTER(DecodeOpts)]
@@ -90,6 +93,7 @@ def load() -> C.CDLL:
     lib.mw_frame_energy_db.argtypes = [vp, f32p, C.c_int64, C.c_int, C.c_int, f32p, C.c_int64]
     lib.mw_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mw_profile_cross_attention.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+    lib.mw_profile_decode_gemvs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
     lib.mw_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.mw_synchronize.argtypes = [vp]
     for name in SYMBOLS:

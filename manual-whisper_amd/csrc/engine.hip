@@ -108,6 +108,7 @@ struct mw_ctx {
     int *forced = nullptr, *out_ids = nullptr, *out_len = nullptr, *finished = nullptr;
     int forced_cap = 0;
     float* xpartial = nullptr; int* xtickets = nullptr;    // cross-attention key-range partials + ticket counters
+    float* dgpartial = nullptr;                            // partial tiles of the projections of 33..128 sequences
     float* skpartial = nullptr; int* sktickets = nullptr;  // split-K partial tiles + ticket counters of the residual projections
     // beam search (allocated on first use)
     float *bm_sum_lp = nullptr, *bm_fin_lp = nullptr, *bm_part_m = nullptr, *bm_part_s = nullptr, *bm_part_v = nullptr;
@@ -305,6 +306,7 @@ static int alloc_work(mw_ctx* ctx) {
     ALLOC(ctx->xpartial, xrows * H * kXattnSplit * 68); ALLOC(ctx->xtickets, xrows * H, true);
     const size_t seq_groups = (B + 15) / 16;                          // batches beyond 32 run as groups of 16 inside a launch
     ALLOC(ctx->skpartial, splitk_partial_floats(D) * seq_groups); ALLOC(ctx->sktickets, splitk_groups(D) * seq_groups, true);
+    if (B > 32) ALLOC(ctx->dgpartial, decgemm_partial_floats((int)D, (int)F));
     ctx->forced_cap = d.n_text_ctx;
     ALLOC(ctx->forced, B * (size_t)ctx->forced_cap);
     ALLOC(ctx->out_ids, B * (size_t)d.n_text_ctx); ALLOC(ctx->out_len, B); ALLOC(ctx->finished, B);
@@ -370,13 +372,16 @@ extern "C" void mw_destroy(mw_ctx* ctx) {
     delete ctx;
 }
 
-extern "C" int mw_fork(mw_ctx* parent, mw_ctx** out) {
+extern "C" int mw_fork(mw_ctx* parent, mw_ctx** out) { return mw_fork_sized(parent, parent ? parent->max_batch : 0, out); }
+
+extern "C" int mw_fork_sized(mw_ctx* parent, int max_batch, mw_ctx** out) {
     if (!parent || !out) return MW_ERR_ARG;
     *out = nullptr;
     if (!parent->finalized) return fail(parent, MW_ERR_STATE, "mw_fork: the parent must be finalized first");
     if (parent->parent) return fail(parent, MW_ERR_ARG, "mw_fork: fork from the original engine, not from a fork");
+    if (max_batch < 1 || max_batch > 128) return fail(parent, MW_ERR_ARG, "mw_fork_sized: max_batch must be in 1..128");
     mw_ctx* ctx = new mw_ctx();
-    ctx->d = parent->d; ctx->device = parent->device; ctx->max_batch = parent->max_batch;
+    ctx->d = parent->d; ctx->device = parent->device; ctx->max_batch = max_batch;
     ctx->use_graph = parent->use_graph; ctx->check_every = parent->check_every; ctx->use_prefill = parent->use_prefill;
     ctx->skip_done = parent->skip_done;
     ctx->parent = parent; ctx->finalized = true;
@@ -773,27 +778,33 @@ static int run_encoder(mw_ctx* ctx, int B) {
     return MW_OK;
 }
 
-static int run_cross_kv(mw_ctx* ctx, int B) {
+// Cross-attention K/V of the B sequences encoded last, for every decoder layer, into the cache of `dst` (this
+// context, or another context of the same model on the same GPU) at sequences slot0 .. slot0 + B - 1.
+static int run_cross_kv(mw_ctx* ctx, int B, mw_ctx* dst = nullptr, int slot0 = 0) {
+    if (!dst) dst = ctx;
     const mw_model_desc& d = ctx->d;
     const int D = d.d_model, H = d.n_heads, T = d.n_audio_ctx, M = B * T;
-    const size_t per_layer = (size_t)ctx->max_batch * T * D;
+    const size_t per_layer = (size_t)dst->max_batch * T * D;
+    const size_t at_slot = (size_t)slot0 * T * D;              // [L][max_batch][H][T][64]: a sequence is H*T*64 = T*D elements
     for (int li = 0; li < d.dec_layers; ++li) {
         GemmParams p = gemm_base(ctx->enc_out, D, ctx->ckv_w + (size_t)li * 2 * D * D, D, M, 2 * D, D, ctx->ckv_b + (size_t)li * 2 * D);
         if (ctx->fp8) {           // encoder output rows as the final LayerNorm quantised them (xn8, xs)
             p.A = reinterpret_cast<const f16*>(ctx->xn8); p.W = reinterpret_cast<const f16*>(ctx->ckv_w8 + (size_t)li * 2 * D * D);
             p.f8 = 1; p.a_scale = ctx->xs; p.w_scale = ctx->ckv_ws + (size_t)li * 2 * D;
         }
-        p.out_mode = OUT_KV_SPLIT; p.k = ctx->crossK + li * per_layer; p.v = ctx->crossV + li * per_layer;
+        p.out_mode = OUT_KV_SPLIT;
         if (ctx->kv8) {
-            const size_t per_layer_rows = (size_t)ctx->max_batch * T * H;
-            p.out_mode = OUT_KV_SPLIT8; p.k8 = ctx->crossK8 + li * per_layer; p.v8 = ctx->crossV8 + li * per_layer;
-            p.ks = ctx->crossKs + li * per_layer_rows; p.vs = ctx->crossVs + li * per_layer_rows;
+            const size_t per_layer_rows = (size_t)dst->max_batch * T * H, rows_at_slot = (size_t)slot0 * T * H;
+            p.out_mode = OUT_KV_SPLIT8; p.k8 = dst->crossK8 + li * per_layer + at_slot; p.v8 = dst->crossV8 + li * per_layer + at_slot;
+            p.ks = dst->crossKs + li * per_layer_rows + rows_at_slot; p.vs = dst->crossVs + li * per_layer_rows + rows_at_slot;
+        } else {
+            p.k = dst->crossK + li * per_layer + at_slot; p.v = dst->crossV + li * per_layer + at_slot;
         }
         p.T = T; p.Tpad = T; p.H = H; p.D = D;
         launch_gemm(p, ctx->stream);
     }
     HIPCHK(hipGetLastError());
-    ctx->enc_batch = B;
+    if (dst == ctx) ctx->enc_batch = B;
     return MW_OK;
 }
 
@@ -864,43 +875,50 @@ static void enqueue_step_tail(mw_ctx* ctx, int B, bool want_logits, const Finali
     else launch_dec_finalize(fp, B, s);
 }
 
-// One greedy step: 8 launches per layer + final norm + logits + token bookkeeping.
-static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int max_keys, const BeamParams* beam = nullptr) {
+// The launches of decoder layer `li` for one position: six weight-streaming projections (GEMVs) and the two
+// attention launches.  `parts`: kLayerGemv, kLayerAttn or both (the measurement entry points time them apart).
+enum { kLayerGemv = 1, kLayerAttn = 2 };
+static void enqueue_layer(mw_ctx* ctx, int li, int B, bool want_logits, const FinalizeParams& fp, int max_keys, const BeamParams* beam,
+                          int parts = kLayerGemv | kLayerAttn) {
     const mw_model_desc& d = ctx->d;
     const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, Tc = d.n_text_ctx;
     hipStream_t s = ctx->stream;
     const float qscale = 1.0f / sqrtf((float)kHeadDim);
     const size_t self_layer = (size_t)ctx->max_batch * D * Tc;
+    const bool gemv = parts & kLayerGemv, attn = parts & kLayerAttn;
     auto base = [&](int N, int K, const LinearW& w) {
         GemvParams p{};
         p.B = B; p.N = N; p.K = K; p.W = w.w; p.W8 = w.w8; p.w_scale = w.ws; p.bias = w.b; p.scale = 1.f; p.scale_ncols = 0; p.gelu = 0;
         p.H = H; p.D = D; p.Tctx = Tc; p.st = ctx->st; p.ln_scratch = ctx->dxn; p.nv = 16;
         p.sk_partial = ctx->skpartial; p.sk_partial_floats = splitk_partial_floats(D);
         p.sk_tickets = ctx->sktickets; p.sk_groups = splitk_groups(D);
+        p.dg_partial = ctx->dgpartial; p.dg_partial_floats = decgemm_partial_floats(D, F); p.dg_groups = splitk_groups(D) * ((ctx->max_batch + 15) / 16);
         return p;
     };
-    for (int li = 0; li < d.dec_layers; ++li) {
-        const DecLayerW& l = ctx->dec[li];
-        f16* sk = ctx->selfK + li * self_layer; f16* sv = ctx->selfV + li * self_layer;
-        {   // LN1 + QKV; k/v go straight into the cache at the current position
-            GemvParams p = base(3 * D, D, l.qkv);
-            p.x32 = ctx->dx; p.ln_g = l.ln1.g; p.ln_b = l.ln1.b; p.scale = qscale; p.scale_ncols = D;
-            p.out_mode = GV_QKV; p.out16 = ctx->dq; p.kcache = sk; p.vcache = sv;
-            launch_gemv(p, s);
-        }
-        launch_dec_self_attn(ctx->dq, sk, sv, ctx->datt, B, H, Tc, ctx->st, s, beam ? beam->src_rows : nullptr, max_keys);
-        {   GemvParams p = base(D, D, l.out); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
-        {   // LN2 + cross-attention query
-            GemvParams p = base(D, D, l.cq);
-            p.x32 = ctx->dx; p.ln_g = l.ln2.g; p.ln_b = l.ln2.b; p.scale = qscale; p.scale_ncols = D;
-            p.out_mode = GV_F16; p.out16 = ctx->dq;
-            launch_gemv(p, s);
-        }
-        // sequences that have ended (recordings whose beam search is complete) are skipped: their next token is
-        // end-of-text whatever the step computes
-        // (not when the caller asked for the logits of every position: those are then the model's own throughout)
+    const DecLayerW& l = ctx->dec[li];
+    f16* sk = ctx->selfK + li * self_layer; f16* sv = ctx->selfV + li * self_layer;
+    if (gemv) {   // LN1 + QKV; k/v go straight into the cache at the current position
+        GemvParams p = base(3 * D, D, l.qkv);
+        p.x32 = ctx->dx; p.ln_g = l.ln1.g; p.ln_b = l.ln1.b; p.scale = qscale; p.scale_ncols = D;
+        p.out_mode = GV_QKV; p.out16 = ctx->dq; p.kcache = sk; p.vcache = sv;
+        launch_gemv(p, s);
+    }
+    if (attn) launch_dec_self_attn(ctx->dq, sk, sv, ctx->datt, B, H, Tc, ctx->st, s, beam ? beam->src_rows : nullptr, max_keys);
+    if (gemv) { GemvParams p = base(D, D, l.out); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
+    if (gemv) {   // LN2 + cross-attention query
+        GemvParams p = base(D, D, l.cq);
+        p.x32 = ctx->dx; p.ln_g = l.ln2.g; p.ln_b = l.ln2.b; p.scale = qscale; p.scale_ncols = D;
+        p.out_mode = GV_F16; p.out16 = ctx->dq;
+        launch_gemv(p, s);
+    }
+    // sequences that have ended (recordings whose beam search is complete) are skipped: their next token is
+    // end-of-text whatever the step computes
+    // (not when the caller asked for the logits of every position: those are then the model's own throughout)
+    if (attn) {
         if (beam) cross_attention(ctx, li, ctx->dq, ctx->datt, B, beam->beam, 0, (ctx->skip_done && ctx->can_end) ? beam->completed : nullptr, beam->beam);
         else cross_attention(ctx, li, ctx->dq, ctx->datt, B, 1, 0, (ctx->skip_done && ctx->can_end && !want_logits) ? fp.finished : nullptr, 1);
+    }
+    if (gemv) {
         {   GemvParams p = base(D, D, l.co); p.xin16 = ctx->datt; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
         {   // LN3 + fc1 + GELU
             GemvParams p = base(F, D, l.fc1);
@@ -909,6 +927,11 @@ static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizePar
         }
         {   GemvParams p = base(D, F, l.fc2); p.xin16 = ctx->dhid; p.out_mode = GV_RESID; p.out32 = ctx->dx; launch_gemv(p, s); }
     }
+}
+
+// One greedy step: 8 launches per layer + final norm + logits + token bookkeeping.
+static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int max_keys, const BeamParams* beam = nullptr) {
+    for (int li = 0; li < ctx->d.dec_layers; ++li) enqueue_layer(ctx, li, B, want_logits, fp, max_keys, beam);
     enqueue_step_tail(ctx, B, want_logits, fp, beam);
 }
 
@@ -1256,6 +1279,49 @@ extern "C" int mw_transcribe_batch(mw_ctx* ctx, const float* pcm, int batch, int
     return MW_OK;
 }
 
+// Encoder half of a pass on one context, decoder half on another: log-mel, encoder and cross K/V of `batch`
+// chunks run on `ctx` (its stream, its workspaces), the K/V land in the cache of `dst` at sequences
+// slot0 .. slot0 + batch - 1.  Returns when they are complete.
+extern "C" int mw_encode_into(mw_ctx* ctx, const float* pcm, int batch, mw_ctx* dst, int slot0) {
+    if (!ctx) return MW_ERR_ARG;
+    int r = check_batch(ctx, batch, "mw_encode_into");
+    if (r) return r;
+    if (!pcm || !dst) return fail(ctx, MW_ERR_ARG, "mw_encode_into: null argument");
+    const mw_ctx* root_a = ctx->parent ? ctx->parent : ctx;
+    const mw_ctx* root_b = dst->parent ? dst->parent : dst;
+    if (root_a != root_b) return fail(ctx, MW_ERR_ARG, "mw_encode_into: both contexts must share weights (an engine and its forks)");
+    if (slot0 < 0 || slot0 + batch > dst->max_batch)
+        return fail(ctx, MW_ERR_ARG, "mw_encode_into: slot0 + batch must fit the destination's max_batch (" + std::to_string(dst->max_batch) + ")");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const float* src = pcm;
+    if (!is_device_ptr(pcm)) {
+        HIPCHK(hipMemcpyAsync(ctx->pcm_dev, pcm, (size_t)batch * kChunkSamples * 4, hipMemcpyHostToDevice, s));
+        src = ctx->pcm_dev;
+    }
+    HIPCHK(hipEventRecord(ctx->ev[0], s));
+    r = run_logmel(ctx, src, batch);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[1], s));
+    r = run_encoder(ctx, batch);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[2], s));
+    r = run_cross_kv(ctx, batch, dst, slot0);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[3], s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < 3; ++i) HIPCHK(hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+    return MW_OK;
+}
+
+extern "C" int mw_set_encoded(mw_ctx* ctx, int batch) {
+    if (!ctx) return MW_ERR_ARG;
+    int r = check_batch(ctx, batch, "mw_set_encoded");
+    if (r) return r;
+    ctx->enc_batch = batch;
+    return MW_OK;
+}
+
 extern "C" int mw_frame_energy_db(mw_ctx* ctx, const float* pcm, int64_t n_samples, int frame, int hop, float* out_db,
                                   int64_t n_frames) {
     if (!ctx) return MW_ERR_ARG;
@@ -1322,5 +1388,38 @@ extern "C" int mw_profile_cross_attention(mw_ctx* ctx, int batch, int iters, flo
     *mean_ms = ms / iters;
     *bytes_per_launch = ctx->kv8 ? 2.0 * batch * d.n_audio_ctx * ((double)d.d_model + 4.0 * d.n_heads)     // K and V: codes + row scales
                                  : 2.0 * batch * d.n_audio_ctx * (double)d.d_model * 2.0;                // K and V, fp16
+    return MW_OK;
+}
+
+// The six weight-streaming projections of a decoder layer (QKV, attention out, cross-attention query and out,
+// MLP in and out), back to back in the order and on the data of a real step, without the two attention launches
+// between them; `iters` layers, cycling through the model's layers.  Reports the mean time per layer (HIP events
+// on the context's stream, launch boundaries included) and the weight bytes a layer's six matrices hold.
+extern "C" int mw_profile_decode_gemvs(mw_ctx* ctx, int batch, int iters, float* mean_ms_per_layer, double* weight_bytes_per_layer) {
+    if (!ctx) return MW_ERR_ARG;
+    int r = check_batch(ctx, batch, "mw_profile_decode_gemvs");
+    if (r) return r;
+    if (iters < 1 || !mean_ms_per_layer || !weight_bytes_per_layer) return fail(ctx, MW_ERR_ARG, "mw_profile_decode_gemvs: bad argument");
+    if (!ctx->opts_set) return fail(ctx, MW_ERR_STATE, "mw_profile_decode_gemvs: call mw_set_decode_opts first");
+    HIPCHK(hipSetDevice(ctx->device));
+    const mw_model_desc& d = ctx->d;
+    FinalizeParams fp = finalize_params(ctx, (int)ctx->prompt.size());
+    // a defined state: position 0 of a fresh decode (the k/v rows the QKV launch files go to cache position 0)
+    std::vector<int32_t> f((size_t)batch * ctx->prompt.size());
+    for (int b = 0; b < batch; ++b) memcpy(&f[(size_t)b * ctx->prompt.size()], ctx->prompt.data(), ctx->prompt.size() * 4);
+    HIPCHK(hipMemcpyAsync(ctx->forced, f.data(), f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    launch_dec_init(fp, batch, (int)ctx->prompt.size(), ctx->max_new, ctx->eot, ctx->stream);
+    for (int i = 0; i < d.dec_layers; ++i) enqueue_layer(ctx, i, batch, false, fp, 1, nullptr, kLayerGemv);       // warm-up pass
+    HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
+    for (int i = 0; i < iters; ++i) enqueue_layer(ctx, i % d.dec_layers, batch, false, fp, 1, nullptr, kLayerGemv);
+    HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[4]));
+    *mean_ms_per_layer = ms / iters;
+    const double D = d.d_model, F = d.ffn_dim;
+    *weight_bytes_per_layer = (6.0 * D * D + 2.0 * D * F) * (ctx->fp8 ? 1.0 : 2.0);
     return MW_OK;
 }

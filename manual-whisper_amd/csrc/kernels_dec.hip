@@ -12,9 +12,51 @@
 
 #include <stdlib.h>
 
+#include <mutex>
+
 namespace mw {
 
 namespace {
+
+// Streamed-once loads.  Decoder weights, the token embedding of the logits product and the cross-attention K/V
+// cache are each read exactly once per step and a step moves far more than the 256 MiB Infinity Cache holds, so
+// nothing is gained by keeping them in the caches: the non-temporal policy (`nt`) lets the lines pass through.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ uint4 load16(const void* p) {
+    u32x4 v;
+    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    else v = *reinterpret_cast<const u32x4*>(p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+template <bool NT>
+__device__ __forceinline__ half8 load_half8(const void* p) {
+    const uint4 u = load16<NT>(p);
+    return *reinterpret_cast<const half8*>(&u);
+}
+template <bool NT>
+__device__ __forceinline__ uint2 load8(const void* p) {
+    u32x2 v;
+    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    else v = *reinterpret_cast<const u32x2*>(p);
+    return make_uint2(v[0], v[1]);
+}
+#ifdef MW_NT_GEMV
+constexpr bool kNtGemv = MW_NT_GEMV;
+#else
+constexpr bool kNtGemv = false;
+#endif
+#ifdef MW_NT_XATTN
+constexpr bool kNtXattn = MW_NT_XATTN;
+#else
+constexpr bool kNtXattn = false;
+#endif
+#ifdef MW_NT_LOGITS
+constexpr bool kNtLogits = MW_NT_LOGITS;
+#else
+constexpr bool kNtLogits = false;
+#endif
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float wave_sum(float v) {
@@ -134,7 +176,7 @@ __global__ __launch_bounds__(XV > 0 ? 512 : 1024, (XV > 0 && R == 1 && MT == 1) 
         const int ks = wave + NW * c;
         kval[c] = ks < nks;
 #pragma unroll
-        for (int r = 0; r < R; ++r) wreg[r][c] = *reinterpret_cast<const uint4*>(wp[r] + min(ks, nks - 1) * 64);
+        for (int r = 0; r < R; ++r) wreg[r][c] = load16<kNtGemv>(wp[r] + min(ks, nks - 1) * 64);
     }
     // epilogue operands: wave r finishes row tile r (the position too: read here, it costs no round trip of its own)
     const int pos = (p.out_mode == GV_QKV && p.st) ? p.st->pos : 0;
@@ -316,7 +358,7 @@ __global__ __launch_bounds__(kSplitKWaves * 64) void gemv_splitk_kernel(GemvPara
         const int kstep = min(ks, kend - 1);
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            wreg[r][c] = *reinterpret_cast<const uint4*>(wbase + (long)(n0 + r * 16 + fr) * wrow_bytes + kstep * 64 + fg * 16);
+            wreg[r][c] = load16<kNtGemv>(wbase + (long)(n0 + r * 16 + fr) * wrow_bytes + kstep * 64 + fg * 16);
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -418,6 +460,162 @@ __global__ __launch_bounds__(kSplitKWaves * 64) void gemv_splitk_kernel(GemvPara
     }
 }
 
+// ------------------------------------------------------------------ projections for 33..128 sequences
+// out[b][n] = epi( sum_k X[b][k] * W[n][k] ) for all B <= 16*MT sequences of a decode group in ONE pass over the
+// weights.  gemv_kernel serves such batches as groups of 32 inside a launch: every 16 weight rows fetch the whole
+// activation matrix again, and at 128 sequences that is what a projection costs (N/16 * B * K * 2 bytes through
+// the L1s: 105 MB for the MLP's first matrix, 14-20 us), not its 3-13 MB of weights.
+// Here a workgroup owns 16*RT weight rows and ONE of S ranges of K for ALL sequences.  Its activation slice
+// ([16*MT][range] fp16) is staged in LDS once, by LDS-DMA; wave (rt, mg) of the 8 multiplies row tile rt by the
+// MT/MG sequence tiles of its group mg over the whole range: the weight fragments go from global memory straight
+// to the MFMA A operand (all loads issued up front, behind the DMA), the activation fragments come from LDS,
+// and no sum crosses waves.  The activation matrix is thus read N/(16*RT) times in total.  S > 1: the S partial
+// tiles of a row group are merged by the workgroup that arrives last, in index order, with the ticket hand-off
+// of gemv_splitk_kernel (every wave publishes its tiles with agent-scope stores and drains them, a workgroup
+// barrier, one ticket per workgroup, the last arriver's waves read their own tiles back with agent-scope loads
+// behind a second barrier).  Input rows are fp16 (the LayerNorm is its own launch at these batch sizes).
+// Measured at 128 sequences, large-v3 shapes, per launch with its boundary (tools/gemv_bench): QKV 14.4 us
+// (grouped gemv_kernel 16.8), MLP in 13.4 (20.4), MLP out 18.8 (20.6), the square projections 9.5-9.9 (9.3-9.6):
+// what is left is the chain of round trips (load, publish, ticket, merge, store), not bytes.
+constexpr int kDecGemmWaves = 8;
+
+// LDS image of the activation slice: 16-byte pieces, kDecPPS(KR) slots per row (the row's pieces at the longest
+// range plus one pad slot, so that the 16 rows of an MFMA operand start in 16 different bank groups), filled by
+// LDS-DMA in slot order (a wave instruction writes 64 consecutive slots).
+template <int KR, bool W8> constexpr int dec_gemm_pps() { return KR * ((W8 ? 64 : 32) / 8) + 1; }
+template <int MT, int KR, bool W8> constexpr int dec_gemm_lds_bytes() {
+    return (16 * MT * dec_gemm_pps<KR, W8>() + kDecGemmWaves * 64 - 1) / (kDecGemmWaves * 64) * (kDecGemmWaves * 64) * 16;
+}
+
+template <int MT, int RT, int KR, bool W8>
+__global__ __launch_bounds__(kDecGemmWaves * 64) void gemm_dec_kernel(GemvParams p, int ks_per) {
+    constexpr int NW = kDecGemmWaves, MG = NW / RT, TPW = MT / MG;     // tiles of 16 sequences per wave
+    constexpr int KSTEP = W8 ? 64 : 32, XF = W8 ? 2 : 1;
+    constexpr int PPS = dec_gemm_pps<KR, W8>();
+    static_assert(NW % RT == 0 && MT % MG == 0 && TPW >= 1, "8 waves = RT row tiles x MG sequence groups");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int rt = wave % RT, mg = wave / RT;
+    const int S = gridDim.y, split = blockIdx.y, rg = blockIdx.x;
+    const int n0 = rg * 16 * RT;
+    const int nks = p.K / KSTEP;
+    const int k0 = split * ks_per;
+    const int nk = min(nks, k0 + ks_per) - k0;          // >= 1: the launcher never creates an empty range
+
+    // ---- activation slice -> LDS by LDS-DMA: slot s = row * PPS + piece; slots past the range (and the pad slot)
+    // repeat the row's last piece, rows >= B repeat the last sequence (never stored)
+    {
+        constexpr int NI = dec_gemm_lds_bytes<MT, KR, W8>() / 16 / (NW * 64);
+        const int ppr = nk * (KSTEP / 8);
+        const f16* xbase = p.xin16 + (long)k0 * KSTEP;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int slot = (j * NW + wave) * 64 + lane;
+            const int r = slot / PPS, c8 = slot - r * PPS;             // PPS is a compile-time constant
+            const f16* src = xbase + (long)min(r, p.B - 1) * p.K + min(c8, ppr - 1) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + (j * NW + wave) * 1024), 16, 0, 0);
+        }
+    }
+    // ---- weights of this wave's row tile over the whole range, straight into the MFMA operand registers
+    const long wrow = min(n0 + rt * 16 + fr, p.N - 1);
+    const char* wp = (W8 ? reinterpret_cast<const char*>(p.W8) + wrow * p.K : reinterpret_cast<const char*>(p.W) + wrow * p.K * 2) +
+                     (long)k0 * 64 + fg * 16;
+    uint4 wreg[KR];
+#pragma unroll
+    for (int c = 0; c < KR; ++c) wreg[c] = load16<kNtGemv>(wp + min(c, nk - 1) * 64);
+    const int pos = (p.out_mode == GV_QKV && p.st) ? p.st->pos : 0;     // read here: no round trip of its own later
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the compiler does not count the LDS-DMA
+    __syncthreads();
+    const char* xs = smem;
+
+    float4v acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = float4v{0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < KR; ++c) {
+        if (c < nk) {                                   // the same for every lane of the workgroup
+            half8 wf[XF];
+            if constexpr (W8) e4m3x16_to_f16(wreg[c], wf[0], wf[XF - 1]);
+            else wf[0] = *reinterpret_cast<half8*>(&wreg[c]);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int h = 0; h < XF; ++h) {
+                    const half8 xf = *reinterpret_cast<const half8*>(xs + (((mg * TPW + t) * 16 + fr) * PPS + c * (KSTEP / 8) + fg * XF + h) * 16);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[h], xf, acc[t], 0, 0, 0);
+                }
+        }
+    }
+    // lane holds out[(mg*TPW + t)*16 + fr][n .. n+3] of this K range, n = n0 + rt*16 + 4*fg
+    if (S > 1) {
+        // slab[rg][split][wave][TPW][64 lanes] float4: every store and load 16 bytes per lane, 1 KiB contiguous per
+        // wave, write-through / L1-bypassing (sc1: aux 16); narrower sc1 stores cost a fabric write each
+        const long slab_floats = (long)S * (NW * TPW * 256);
+        const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc(p.sk_partial + (long)rg * slab_floats, 0,
+                                                                             (int)(slab_floats * 4), 0x00020000);
+        const int mine = (((split * NW + wave) * TPW) * 64 + lane) * 16;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const u32x4 bits = {__float_as_uint(acc[t][0]), __float_as_uint(acc[t][1]), __float_as_uint(acc[t][2]), __float_as_uint(acc[t][3])};
+            __builtin_amdgcn_raw_buffer_store_b128(bits, slab, mine + t * 1024, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's tiles have left the CU
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(p.sk_tickets + rg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+        __syncthreads();
+        if (!s_last) return;
+        // last arriver: all S partials of this row group are complete; every wave sums its own tiles in index order
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = float4v{0, 0, 0, 0};
+        for (int i = 0; i < S; ++i) {
+            const int theirs = (((i * NW + wave) * TPW) * 64 + lane) * 16;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(slab, theirs + t * 1024, 0, 16);
+                acc[t][0] += __uint_as_float(bits[0]); acc[t][1] += __uint_as_float(bits[1]);
+                acc[t][2] += __uint_as_float(bits[2]); acc[t][3] += __uint_as_float(bits[3]);
+            }
+        }
+        if (tid == 0) __hip_atomic_store(p.sk_tickets + rg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    const int n = n0 + rt * 16 + 4 * fg;
+    if (n >= p.N) return;
+    const float4 bias4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+    const float4 ws4 = W8 ? *reinterpret_cast<const float4*>(p.w_scale + n) : make_float4(1, 1, 1, 1);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int m = (mg * TPW + t) * 16 + fr;
+        if (m >= p.B) continue;
+        float4v o = {bias4.x, bias4.y, bias4.z, bias4.w};
+        o[0] += acc[t][0] * ws4.x; o[1] += acc[t][1] * ws4.y; o[2] += acc[t][2] * ws4.z; o[3] += acc[t][3] * ws4.w;
+        if (n < p.scale_ncols) o *= p.scale;
+        if (p.gelu) { o[0] = gelu_erf(o[0]); o[1] = gelu_erf(o[1]); o[2] = gelu_erf(o[2]); o[3] = gelu_erf(o[3]); }
+        if (p.out_mode == GV_RESID) {
+            float4* dst = reinterpret_cast<float4*>(p.out32 + (long)m * p.N + n);
+            const float4 r4 = *dst;
+            *dst = make_float4(r4.x + o[0], r4.y + o[1], r4.z + o[2], r4.w + o[3]);
+        } else {
+            const half4 h = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+            if (p.out_mode == GV_F16) {
+                *reinterpret_cast<half4*>(p.out16 + (long)m * p.N + n) = h;
+            } else {   // GV_QKV: q -> out16 [B][D]; k, v -> this layer's cache at the current position
+                const int sec = n / p.D, nn = n - sec * p.D;
+                if (sec == 0) {
+                    *reinterpret_cast<half4*>(p.out16 + (long)m * p.D + nn) = h;
+                } else {
+                    f16* cache = sec == 1 ? p.kcache : p.vcache;
+                    const int hh = nn >> 6, e = nn & 63;
+                    *reinterpret_cast<half4*>(cache + (((long)m * p.H + hh) * p.Tctx + pos) * 64 + e) = h;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ logits + partial argmax
 // logits[b][n] = xn[b] . E[n] over the tied token embedding (modeling_whisper.py:1080).
 // Workgroup = 8 waves, each a tile of 16 vocabulary rows over the full K; the normalised
@@ -446,7 +644,7 @@ __global__ __launch_bounds__(512) void logits_kernel(GemvParams p) {
     uint4 wa[LCH], wb[LCH];
     auto wload = [&](uint4 (&dst)[LCH], int kb) {
 #pragma unroll
-        for (int c = 0; c < LCH; ++c) dst[c] = *reinterpret_cast<const uint4*>(wp + min(kb + c, nks - 1) * 32);
+        for (int c = 0; c < LCH; ++c) dst[c] = load16<kNtLogits>(wp + min(kb + c, nks - 1) * 32);
     };
     wload(wa, 0);
     wload(wb, LCH);
@@ -594,7 +792,7 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
 
     half8 kv[RPT];
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) kv[i] = *reinterpret_cast<const half8*>(kb + row_off(i));
+    for (int i = 0; i < RPT; ++i) kv[i] = load_half8<(S > 1) && kNtXattn>(kb + row_off(i));
     float qv[8];
     {
         const half8 qh = *reinterpret_cast<const half8*>(q + (long)bh * 64 + dc * 8);
@@ -616,7 +814,7 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
         mx = fmaxf(mx, sv[i]);
     }
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) kv[i] = *reinterpret_cast<const half8*>(vb + row_off(i));
+    for (int i = 0; i < RPT; ++i) kv[i] = load_half8<(S > 1) && kNtXattn>(vb + row_off(i));
     // ---- softmax over all rows of the workgroup
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
@@ -745,7 +943,7 @@ __global__ __launch_bounds__(NT, 5) void cross_attn8_kernel(const f16* __restric
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int r = min(rg + NG * i, n - 1);
-        kv[i] = *reinterpret_cast<const uint2*>(kb + (long)r * 64);
+        kv[i] = load8<kNtXattn>(kb + (long)r * 64);
         rs[i] = ksb[r];
     }
     float qv[8];
@@ -772,7 +970,7 @@ __global__ __launch_bounds__(NT, 5) void cross_attn8_kernel(const f16* __restric
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int r = min(rg + NG * i, n - 1);
-        kv[i] = *reinterpret_cast<const uint2*>(vb + (long)r * 64);
+        kv[i] = load8<kNtXattn>(vb + (long)r * 64);
         rs[i] = vsb[r];
     }
     mx = wave_max(mx);
@@ -1356,11 +1554,66 @@ bool launch_splitk(const GemvParams& p, int mt, hipStream_t s) {
     return mt == 1 ? launch_splitk_r<1, 2, false>(p, S, s) : launch_splitk_r<2, 2, false>(p, S, s);
 }
 
+
+// gemm_dec_kernel for 33..128 sequences (fp16 input rows).  Row tiles per workgroup: 4 for wide outputs and long K
+// (fewer passes over the activations), 2 for narrow ones (more row groups); K ranges so that one round of
+// workgroups about fills the CUs and a range fits the registers (KR k-steps) and LDS.  Returns false, having
+// launched nothing, when the shape does not fit (the grouped gemv_kernel takes over).
+template <int MT, int RT, int KR, bool W8>
+void launch_gemm_dec_t(const GemvParams& p, int S, int ks_per, hipStream_t s) {
+    constexpr size_t lds = dec_gemm_lds_bytes<MT, KR, W8>();
+    const dim3 grid((p.N + 16 * RT - 1) / (16 * RT), S), block(kDecGemmWaves * 64);
+    hipLaunchKernelGGL((gemm_dec_kernel<MT, RT, KR, W8>), grid, block, lds, s, p, ks_per);
+}
+
+template <int MT, bool W8>
+bool launch_gemm_dec_mt(const GemvParams& p, hipStream_t s) {
+    constexpr int KSTEP = W8 ? 64 : 32, KR_MAX = W8 ? 8 : 16;         // 512 columns: 132 KB of LDS at 128 sequences
+    if (p.K % KSTEP || p.N % 4 || !p.xin16 || p.ln_g) return false;
+    const int nks = p.K / KSTEP;
+    const bool wide = p.N >= 2048 || p.K > 2048;
+    const int rt = wide ? 4 : 2;
+    const int groups = (p.N + 16 * rt - 1) / (16 * rt);
+    static const int target = getenv("MW_DEC_GEMM_WGS") ? atoi(getenv("MW_DEC_GEMM_WGS")) : 240;
+    int S = max((nks + KR_MAX - 1) / KR_MAX, min(nks, (target + groups / 2) / groups));
+    S = max(1, S);
+    int ks_per = (nks + S - 1) / S;
+    S = (nks + ks_per - 1) / ks_per;
+    if (groups > p.dg_groups || (S > 1 && (!p.dg_partial || !p.sk_tickets || (long)groups * S * 16 * rt * 16 * MT > p.dg_partial_floats)))
+        return false;
+    GemvParams q = p;
+    q.sk_partial = p.dg_partial;                 // this kernel's own, larger slab; the tickets are shared (always left at zero)
+#define MW_DG(RT, KR) launch_gemm_dec_t<MT, RT, KR, W8>(q, S, ks_per, s)
+    if (ks_per <= KR_MAX / 2) { if (wide) MW_DG(4, KR_MAX / 2); else MW_DG(2, KR_MAX / 2); }
+    else { if (wide) MW_DG(4, KR_MAX); else MW_DG(2, KR_MAX); }
+#undef MW_DG
+    return true;
+}
+
+template <int MT, bool W8>
+void prepare_gemm_dec_mt() {
+    constexpr int kDecGemmLds = 144 * 1024;      // the kernel also holds a static word: the whole 160 KiB cannot be dynamic
+    constexpr int KR_MAX = W8 ? 8 : 16;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 2, KR_MAX / 2, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 4, KR_MAX / 2, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 2, KR_MAX, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 4, KR_MAX, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
+}
+
+bool launch_gemm_dec(const GemvParams& p, hipStream_t s) {
+    if (p.B <= 32 || p.B > 128) return false;
+    if (p.B <= 64) return p.W8 ? launch_gemm_dec_mt<4, true>(p, s) : launch_gemm_dec_mt<4, false>(p, s);
+    return p.W8 ? launch_gemm_dec_mt<8, true>(p, s) : launch_gemm_dec_mt<8, false>(p, s);
+}
+
 }  // namespace
 
 int gemv_logits_parts(int N) { return ((N + 15) / 16 + 7) / 8; }
 
-void dec_kernels_prepare() { prepare_mt<1>(); prepare_mt<2>(); }
+void dec_kernels_prepare() {
+    prepare_mt<1>(); prepare_mt<2>();
+    prepare_gemm_dec_mt<4, false>(); prepare_gemm_dec_mt<4, true>(); prepare_gemm_dec_mt<8, false>(); prepare_gemm_dec_mt<8, true>();
+}
 
 void launch_gemv(const GemvParams& p0, hipStream_t s) {
     GemvParams p = p0;
@@ -1374,6 +1627,20 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
         if (mt == 1) hipLaunchKernelGGL(logits_kernel<1>, grid, dim3(512), lds, s, p);
         else hipLaunchKernelGGL(logits_kernel<2>, grid, dim3(512), lds, s, p);
         return;
+    }
+    if (p.B > 32) {
+        // one pass over the weights for all sequences; the LayerNorm (when there is one) as its own launch
+        static const bool dg_off = getenv("MW_DEC_GEMM_OFF") != nullptr;
+        if (!dg_off && p.out_mode != GV_LOGITS) {
+            GemvParams q = p;
+            if (p.ln_g) { q.ln_g = nullptr; q.ln_b = nullptr; q.xin16 = p.ln_scratch; }
+            // shape check first (launch_gemm_dec returns false before launching anything), then the LayerNorm
+            if (q.K % (q.W8 ? 64 : 32) == 0 && q.N % 16 == 0) {
+                if (p.ln_g) launch_layernorm(p.x32, p.ln_g, p.ln_b, p.ln_scratch, nullptr, p.B, p.K, s);
+                if (launch_gemm_dec(q, s)) return;
+                if (p.ln_g) { p = q; }          // the rows are normalised already: the grouped form below reads them
+            }
+        }
     }
     // narrow outputs: 8 rows per workgroup so that at least ~160 workgroups stream weights
     static const int nv_narrow = getenv("MW_NV_NARROW") ? atoi(getenv("MW_NV_NARROW")) : 8;

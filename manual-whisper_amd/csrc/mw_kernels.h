@@ -127,7 +127,12 @@ struct GemvParams {
     // tickets must be zero before the first launch, every launch leaves them zero again); sk_partial_floats and
     // sk_groups are the extents of ONE group of 16 (or 32) sequences, the buffers hold one such block per group
     float* sk_partial; long sk_partial_floats; int* sk_tickets; int sk_groups;
+    // projections of 33..128 sequences (gemm_dec_kernel), optional: partial tiles of its K ranges (dg_partial_floats in
+    // all) and the number of row groups the ticket array covers; it shares sk_tickets
+    float* dg_partial; long dg_partial_floats; int dg_groups;
 };
+// floats of partial-tile scratch that cover every projection of a model (d_model D, MLP width F) at up to 128 sequences
+inline long decgemm_partial_floats(int D, int F) { return (long)(3 * D > F ? 3 * D : F) * 128 * 8; }
 // floats / ints of split-K scratch that cover every residual projection of a model of width D
 inline long splitk_partial_floats(int D) { return (long)(D / 16) * 8 * 2 * 256; }
 inline int splitk_groups(int D) { return D / 16; }

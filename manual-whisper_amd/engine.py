@@ -67,13 +67,14 @@ class Engine:
         self._h = h
         self._forks = []
 
-    def fork(self) -> "Engine":
-        """A second engine on the same GPU sharing these weights (own stream and caches); safe to
-        drive from another thread while this one is busy."""
+    def fork(self, max_batch: Optional[int] = None) -> "Engine":
+        """A second engine on the same GPU sharing these weights (own stream and caches, sized for
+        ``max_batch`` chunks: this engine's by default); safe to drive from another thread while this one is busy."""
         h = C.c_void_p()
-        self._check(self._lib.mw_fork(self._h, C.byref(h)), "mw_fork")
+        max_batch = self.max_batch if max_batch is None else int(max_batch)
+        self._check(self._lib.mw_fork_sized(self._h, max_batch, C.byref(h)), "mw_fork_sized")
         child = object.__new__(Engine)
-        child._lib, child.dims, child.device, child.max_batch = self._lib, self.dims, self.device, self.max_batch
+        child._lib, child.dims, child.device, child.max_batch = self._lib, self.dims, self.device, max_batch
         child.weight_format, child.kv_format = self.weight_format, self.kv_format
         child.opts = self.opts
         child._h = h
@@ -185,6 +186,16 @@ class Engine:
                                         _ptr(out) if want_output else None), "mw_encode")
         return out
 
+    def encode_into(self, pcm, dst: "Engine", slot0: int) -> None:
+        """log-mel + encoder + cross K/V of ``pcm`` [B, 480000] on this engine, the K/V into sequences
+        ``slot0 .. slot0 + B - 1`` of ``dst``'s cache (this engine, its parent or another fork of it)."""
+        B = self._pcm_batch(pcm)
+        self._check(self._lib.mw_encode_into(self._h, _ptr(pcm), B, dst._h, int(slot0)), "mw_encode_into")
+
+    def set_encoded(self, batch: int) -> None:
+        """Sequences 0 .. batch - 1 of this engine's cache have been filled by ``encode_into`` calls."""
+        self._check(self._lib.mw_set_encoded(self._h, int(batch)), "mw_set_encoded")
+
     def decode_greedy(self, batch: int, want_logits: bool = False):
         if self.opts is None:
             raise EngineError("set_decode_options first")
@@ -246,6 +257,13 @@ class Engine:
         ms, nbytes = C.c_float(), C.c_double()
         self._check(self._lib.mw_profile_cross_attention(self._h, batch, iters, C.byref(ms), C.byref(nbytes)),
                     "mw_profile_cross_attention")
+        return ms.value, nbytes.value
+
+    def profile_decode_gemvs(self, batch: int, iters: int = 256):
+        """(mean ms per decoder layer of its six projection launches, weight bytes per layer)."""
+        ms, nbytes = C.c_float(), C.c_double()
+        self._check(self._lib.mw_profile_decode_gemvs(self._h, batch, iters, C.byref(ms), C.byref(nbytes)),
+                    "mw_profile_decode_gemvs")
         return ms.value, nbytes.value
 
     def synchronize(self):

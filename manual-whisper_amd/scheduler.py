@@ -7,8 +7,9 @@ fixed 30 s chunks (the last one zero-padded) and a segment's start/end are its c
 from __future__ import annotations
 
 import queue
+import threading
 from concurrent.futures import ThreadPoolExecutor
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -74,3 +75,128 @@ class EnginePool:
         self._pool.shutdown(wait=True)
         for e in reversed(self.engines):
             e.close()
+
+
+def group_sizes(n_batches: int, group: int) -> List[int]:
+    """n_batches consecutive batches -> sizes of the decode groups: as few groups as `group` per group allows,
+    evened out so that no group is more than one batch larger than another."""
+    if n_batches <= 0:
+        return []
+    n_groups = (n_batches + group - 1) // group
+    base, extra = divmod(n_batches, n_groups)
+    return [base + (1 if g < extra else 0) for g in range(n_groups)]
+
+
+class GroupedPool:
+    """Encoder passes of BATCH_SIZE chunks, decoding in groups of several such batches.
+
+    The reference's ``model.transcribe(audio, batch_size=BATCH_SIZE)`` (transcribe.py:123) sends BATCH_SIZE chunks
+    through the model at a time.  Here the encoder half of a pass (log-mel, encoder, cross K/V) keeps that
+    granularity, on `n_encoders` engines of `batch` chunks each, but writes its K/V straight into the cache of one of
+    `n_decoders` decode engines of `group * batch` sequences; a decode engine runs the greedy loop over a whole
+    group at once, so every decoder weight is streamed from HBM once per step for `group` batches instead of once
+    per batch, and the decode launches (latency-bound at 16 sequences) carry `group` times the work.  While one
+    group decodes, the encoders fill the other decode engine's cache.  Chunks are independent: the ids are those
+    of batch-by-batch passes.
+    """
+
+    def __init__(self, engine, batch: int = 16, group: int = 4, n_encoders: int = 2, n_decoders: int = 2):
+        if batch < 1 or group < 1 or n_encoders < 1 or n_decoders < 1:
+            raise ValueError("batch, group, n_encoders and n_decoders must be >= 1")
+        if batch * group > 128:
+            raise ValueError("a decode group holds at most 128 sequences")
+        self.batch, self.group = int(batch), int(group)
+        self.root = engine
+        # the engine that owns the weights serves as the first encoder when its own workspaces are large enough
+        first = [engine] if engine.max_batch >= batch else []
+        self.encoders = first + [engine.fork(batch) for _ in range(n_encoders - len(first))]
+        self.decoders = [engine.fork(batch * group) for _ in range(n_decoders)]
+        self._enc_pool = ThreadPoolExecutor(max_workers=n_encoders)
+        self._dec_pool = ThreadPoolExecutor(max_workers=n_decoders)
+        self._free_enc: "queue.Queue" = queue.Queue()
+        for e in self.encoders:
+            self._free_enc.put(e)
+
+    @property
+    def engines(self):
+        return self.encoders + self.decoders
+
+    def set_decode_options(self, opts):
+        for e in {id(e): e for e in [self.root] + self.engines}.values():
+            e.set_decode_options(opts)
+
+    def map(self, batches: Sequence) -> list:
+        """Transcribe every batch (numpy on the host or a tensor on the engine's GPU, at most `batch` chunks each);
+        returns [(ids, lens)] in the order of ``batches``."""
+        n = len(batches)
+        sizes = group_sizes(n, self.group)
+        n_groups, nd = len(sizes), len(self.decoders)
+        group_of, slot_of, members = [], [], []
+        i = 0
+        for g, sz in enumerate(sizes):
+            slot = 0
+            members.append(list(range(i, i + sz)))
+            for _ in range(sz):
+                rows = int(batches[i].shape[0])
+                if rows > self.batch:
+                    raise ValueError(f"batch {i} has {rows} chunks; the encoders take {self.batch}")
+                group_of.append(g)
+                slot_of.append(slot)
+                slot += rows
+                i += 1
+        encoded = [threading.Event() for _ in range(n)]
+        cache_free = [threading.Event() for _ in range(n_groups)]      # group g's decode engine has finished group g - nd
+        for g in range(min(nd, n_groups)):
+            cache_free[g].set()
+        results: List[Optional[tuple]] = [None] * n
+        errors: list = []
+
+        def encode(i):
+            g = group_of[i]
+            try:
+                cache_free[g].wait()
+                if errors:
+                    return
+                enc = self._free_enc.get()
+                try:
+                    enc.encode_into(batches[i], self.decoders[g % nd], slot_of[i])
+                finally:
+                    self._free_enc.put(enc)
+            except BaseException as e:         # noqa: BLE001 - handed to the caller below
+                errors.append(e)
+            finally:
+                encoded[i].set()
+
+        def decode(g):
+            dec = self.decoders[g % nd]
+            try:
+                for i in members[g]:
+                    encoded[i].wait()
+                if not errors:
+                    rows = sum(int(batches[i].shape[0]) for i in members[g])
+                    dec.set_encoded(rows)
+                    ids, lens, _ = dec.decode_greedy(rows)
+                    for i in members[g]:
+                        a, b = slot_of[i], slot_of[i] + int(batches[i].shape[0])
+                        results[i] = (ids[a:b].copy(), lens[a:b].copy())
+            except BaseException as e:         # noqa: BLE001
+                errors.append(e)
+            finally:
+                if g + nd < n_groups:
+                    cache_free[g + nd].set()
+
+        enc_f = [self._enc_pool.submit(encode, i) for i in range(n)]
+        dec_f = [self._dec_pool.submit(decode, g) for g in range(n_groups)]
+        for f in enc_f + dec_f:
+            f.result()
+        if errors:
+            raise errors[0]
+        return results
+
+    def close(self):
+        self._enc_pool.shutdown(wait=True)
+        self._dec_pool.shutdown(wait=True)
+        for e in reversed(self.engines):
+            if e is not self.root:
+                e.close()
+        self.root.close()

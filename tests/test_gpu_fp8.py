@@ -174,6 +174,12 @@ def test_config5_large_v3_fp8_one_chunk_vs_oracle():
         hi, _ = eng.transcribe_batch(pcm[16:])
         assert (la == 12).all() and (a[:16] == lo).all() and (a[16:] == hi).all()
         assert len({tuple(r) for r in a}) > 1
+        # configs[4] as the benchmark runs it (32 chunks in one pass): 2 of the 32 rows x 32 sampled tokens against
+        # the oracle on the engine's own encoder output (identical fp32 inputs -> identical codes)
+        from test_gpu_configs import _rows_vs_oracle
+        first_err, path_err, forced_err, _ = _rows_vs_oracle(eng, orc, dims, pcm, [3, 28], 32, enc_rows="engine")
+        assert first_err < LOGIT_ATOL, first_err
+        assert path_err < 2 * LOGIT_ATOL and forced_err < 2 * LOGIT_ATOL, (path_err, forced_err)
     finally:
         eng.close()
 

@@ -459,7 +459,7 @@ def test_batches_beyond_32_run_as_groups(weight_format):
         eng.logmel(pcm[3:6], want_output=False)
         eng.encode(3, want_output=False)
         small = eng.decode_beam(3, 5)
-        assert (big[0][3:6] == small[0]).all() and np.abs(big[2][3:6] - small[2]).max() < 1e-5
+        assert (big[0][3:6] == small[0]).all() and np.abs(big[2][3:6] - small[2]).max() < 1e-3      # 45 and 15 sequences take different projection kernels (other summation order)
     finally:
         eng.close()
 
@@ -479,3 +479,40 @@ def test_model_coalesces_batches_without_changing_ids():
     assert len(res[1]["segments"]) == 40
     assert [s["tokens"] for s in res[1]["segments"]] == [s["tokens"] for s in res[4]["segments"]]
     assert res[4]["segments"][-1]["end"] == pytest.approx(30 * 39 + 7)
+
+
+def test_grouped_pool_encodes_in_batches_and_decodes_in_groups():
+    """GroupedPool: encoder passes of 4 chunks on two engines, decoding in groups of up to 3 such batches on two
+    decode engines (mw_encode_into writes the cross K/V into the decode engine's cache at the batch's slot): ids and
+    lengths equal those of plain batch-by-batch passes, also with a ragged last batch, a last group that is not
+    full, fewer batches than a group, and sequences that end early."""
+    from manual_whisper_amd.engine import Engine
+    from manual_whisper_amd.scheduler import GroupedPool
+    dims = mw.get_dims("micro")
+    w = synth.make_weights_np(dims, 1234)
+    opts = synthetic_options(dims, max_new=10)
+    plain = Engine(dims, device=0, max_batch=4)
+    plain.load_weights(w)
+    plain.set_decode_options(opts)
+    root = Engine(dims, device=0, max_batch=4)
+    root.load_weights(w)
+    pool = GroupedPool(root, batch=4, group=3, n_encoders=2, n_decoders=2)
+    pool.set_decode_options(opts)
+    try:
+        pcm = synth.make_pcm_np(30, seed=77)
+        pcm[5, 1000:] = 0.0
+        for cuts in ([(0, 4), (4, 8), (8, 12), (12, 16), (16, 20), (20, 24), (24, 28), (28, 30)],      # 8 batches -> groups of 3, 3, 2
+                     [(0, 4), (4, 7)],                                                                  # fewer batches than a group
+                     [(3, 4)]):
+            batches = [pcm[a:b] for a, b in cuts]
+            got = pool.map(batches)
+            assert len(got) == len(batches)
+            for (a, b), (ids, lens) in zip(cuts, got):
+                wi, wl = plain.transcribe_batch(pcm[a:b])
+                assert ids.shape == wi.shape and (ids == wi).all() and (lens == wl).all(), (a, b)
+        assert pool.map([]) == []
+        with pytest.raises(ValueError):
+            pool.map([pcm[:5]])
+    finally:
+        pool.close()
+        plain.close()

@@ -41,6 +41,17 @@ def test_split_chunks_edges():
     assert scheduler.batches_of(5, 2) == [(0, 2), (2, 4), (4, 5)] and scheduler.batches_of(0, 4) == []
 
 
+def test_group_sizes():
+    assert scheduler.group_sizes(0, 4) == []
+    assert scheduler.group_sizes(3, 4) == [3] and scheduler.group_sizes(4, 4) == [4]
+    assert scheduler.group_sizes(5, 4) == [3, 2] and scheduler.group_sizes(20, 4) == [4] * 5
+    assert scheduler.group_sizes(9, 4) == [3, 3, 3] and scheduler.group_sizes(7, 1) == [1] * 7
+    for n in range(1, 40):
+        for g in (1, 2, 4, 8):
+            sz = scheduler.group_sizes(n, g)
+            assert sum(sz) == n and max(sz) <= g and max(sz) - min(sz) <= 1 and len(sz) == (n + g - 1) // g
+
+
 def test_shard_and_pack():
     for n in (0, 1, 7, 120):
         for w in (1, 2, 8):

@@ -32,13 +32,15 @@ int main(int argc, char** argv) {
     const int L = 32;                                     // launches per graph
     const int NWT = getenv("HOT") ? 1 : L;               // HOT=1: every launch reads the same matrix (cache-resident weights)
     dec_kernels_prepare();
-    f16 *W, *xin16, *out16, *lnscr; float *x32, *out32, *bias, *g, *b, *skp; int* skt; DecState* st;
+    f16 *W, *xin16, *out16, *lnscr; float *x32, *out32, *bias, *g, *b, *skp, *dgp; int* skt; DecState* st;
     CK(hipMalloc(&W, (size_t)L * N * K * 2)); CK(hipMalloc(&xin16, (size_t)B * K * 2));
     CK(hipMalloc(&out16, (size_t)B * N * 2)); CK(hipMalloc(&lnscr, (size_t)B * K * 2));
     CK(hipMalloc(&x32, (size_t)B * K * 4)); CK(hipMalloc(&out32, (size_t)B * N * 4)); CK(hipMalloc(&bias, (size_t)N * 4));
     CK(hipMalloc(&g, (size_t)K * 4)); CK(hipMalloc(&b, (size_t)K * 4));
-    CK(hipMalloc(&skp, (size_t)splitk_partial_floats(N) * 4)); CK(hipMalloc(&skt, splitk_groups(N) * 4)); CK(hipMalloc(&st, sizeof(DecState)));
-    CK(hipMemset(skt, 0, splitk_groups(N) * 4)); CK(hipMemset(st, 0, sizeof(DecState))); CK(hipMemset(out32, 0, (size_t)B * N * 4));
+    const int groups16 = (B + 15) / 16;
+    CK(hipMalloc(&skp, (size_t)splitk_partial_floats(N) * groups16 * 4)); CK(hipMalloc(&skt, (size_t)splitk_groups(N) * groups16 * 4)); CK(hipMalloc(&st, sizeof(DecState)));
+    CK(hipMalloc(&dgp, (size_t)decgemm_partial_floats(N, N) * 4));
+    CK(hipMemset(skt, 0, (size_t)splitk_groups(N) * groups16 * 4)); CK(hipMemset(st, 0, sizeof(DecState))); CK(hipMemset(out32, 0, (size_t)B * N * 4));
     fill16<<<(unsigned)(((long)L * N * K + 255) / 256), 256>>>(W, (long)L * N * K, 1u, 0.03f);
     fill16<<<(B * K + 255) / 256, 256>>>(xin16, (long)B * K, 2u, 1.0f);
     fill32<<<(B * K + 255) / 256, 256>>>(x32, (long)B * K, 3u, 1.0f, 0.f);
@@ -53,6 +55,7 @@ int main(int argc, char** argv) {
             p.B = B; p.N = N; p.K = K; p.W = W + (size_t)(l % NWT) * N * K; p.bias = bias; p.scale = 1.f; p.nv = 16; p.st = st;
             p.H = N / 64; p.D = N; p.Tctx = 448; p.ln_scratch = lnscr;
             p.sk_partial = skp; p.sk_partial_floats = splitk_partial_floats(N); p.sk_tickets = skt; p.sk_groups = splitk_groups(N);
+            p.dg_partial = dgp; p.dg_partial_floats = decgemm_partial_floats(N, N); p.dg_groups = splitk_groups(N) * groups16;
             if (mode >= 2) { p.x32 = x32; p.ln_g = g; p.ln_b = b; p.gelu = mode == 3; p.out_mode = GV_F16; p.out16 = out16; }
             else if (mode == 1) { p.xin16 = xin16; p.out_mode = GV_RESID; p.out32 = out32; }
             else { p.xin16 = xin16; p.out_mode = GV_F16; p.out16 = out16; }
