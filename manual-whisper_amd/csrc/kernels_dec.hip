@@ -50,7 +50,7 @@ constexpr bool kNtGemv = false;
 #ifdef MW_NT_XATTN
 constexpr bool kNtXattn = MW_NT_XATTN;
 #else
-constexpr bool kNtXattn = false;
+constexpr bool kNtXattn = true;      // measured: 22.9 -> 22.0 us per launch at 16 sequences, +3.4 % end to end with decode groups of 112
 #endif
 #ifdef MW_NT_LOGITS
 constexpr bool kNtLogits = MW_NT_LOGITS;
@@ -477,6 +477,10 @@ __global__ __launch_bounds__(kSplitKWaves * 64) void gemv_splitk_kernel(GemvPara
 // Measured at 128 sequences, large-v3 shapes, per launch with its boundary (tools/gemv_bench): QKV 14.4 us
 // (grouped gemv_kernel 16.8), MLP in 13.4 (20.4), MLP out 18.8 (20.6), the square projections 9.5-9.9 (9.3-9.6):
 // what is left is the chain of round trips (load, publish, ticket, merge, store), not bytes.
+// Tried and dropped: workgroups of 32 sequences over the whole of K (82 KB of activations in LDS, 160 weight
+// registers per lane, no partial sums for K = 1280): a workgroup then takes in 250-410 KB, and one CU ingests
+// about 25 GB/s however the loads are issued: 13.5 us for the square projections, 29.6 for the MLP's second matrix.
+// Many workgroups with little data each beat few with much, merges included.
 constexpr int kDecGemmWaves = 8;
 
 // LDS image of the activation slice: 16-byte pieces, kDecPPS(KR) slots per row (the row's pieces at the longest
@@ -790,9 +794,17 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
         else return (long)min(rg + NG * i, n - 1) * 64;
     };
 
+    // Self-attention (S == 1: few rows per thread): V is fetched beside K, one round trip instead of two.
+    // Cross-attention keeps one register set: its V loads are issued as soon as the scores have freed it.
+    constexpr bool V_EARLY = S == 1;
     half8 kv[RPT];
+    half8 vv[V_EARLY ? RPT : 1];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) kv[i] = load_half8<(S > 1) && kNtXattn>(kb + row_off(i));
+    if constexpr (V_EARLY) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) vv[i] = *reinterpret_cast<const half8*>(vb + row_off(i));
+    }
     float qv[8];
     {
         const half8 qh = *reinterpret_cast<const half8*>(q + (long)bh * 64 + dc * 8);
@@ -814,7 +826,10 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
         mx = fmaxf(mx, sv[i]);
     }
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) kv[i] = load_half8<(S > 1) && kNtXattn>(vb + row_off(i));
+    for (int i = 0; i < RPT; ++i) {
+        if constexpr (V_EARLY) kv[i] = vv[i];
+        else kv[i] = load_half8<(S > 1) && kNtXattn>(vb + row_off(i));
+    }
     // ---- softmax over all rows of the workgroup
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
@@ -1659,14 +1674,14 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
     else { if (mt == 1) (void)launch_gemv_mt<1, false>(p, s); else (void)launch_gemv_mt<2, false>(p, s); }
 }
 
-template <int RPT>
+template <int NT, int RPT>
 static void launch_self_attn_rpt(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx, const DecState* st,
                                  hipStream_t s, const int* src_rows) {
     if (src_rows)
-        hipLaunchKernelGGL((dec_attn_kernel<512, RPT, 1, true>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st,
+        hipLaunchKernelGGL((dec_attn_kernel<NT, RPT, 1, true>), dim3(B * H), dim3(NT), 0, s, q, kc, vc, out, H, Tctx, 0, st,
                            (float*)nullptr, (int*)nullptr, 1, src_rows, B);
     else
-        hipLaunchKernelGGL((dec_attn_kernel<512, RPT, 1>), dim3(B * H), dim3(512), 0, s, q, kc, vc, out, H, Tctx, 0, st,
+        hipLaunchKernelGGL((dec_attn_kernel<NT, RPT, 1>), dim3(B * H), dim3(NT), 0, s, q, kc, vc, out, H, Tctx, 0, st,
                            (float*)nullptr, (int*)nullptr, 1, (const int*)nullptr, B);
 }
 
@@ -1674,14 +1689,25 @@ int dec_self_attn_bucket(int n_keys) { return n_keys <= 64 ? 0 : n_keys <= 128 ?
 
 void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int Tctx,
                           const DecState* st, hipStream_t s, const int* src_rows, int max_keys) {
-    // 512 threads = 64 row groups; a thread owns RPT cached positions.  The launch is sized for the
+    // NT threads = NT/8 row groups; a thread owns RPT cached positions.  The launch is sized for the
     // keys that can exist (`max_keys` >= position + 1 of every step it will serve): rows past the
     // context only cost duplicate loads, and at the start of a transcript that is most of them.
+    // Few (sequence, head) pairs: 512 threads each, so that the chip holds them all at once with the fewest rows
+    // per thread.  Many (a decode group of 33..128 sequences): 128-thread workgroups with more rows per thread,
+    // 16 of them per CU, so that the whole launch is still resident in one round (2560 workgroups of 512 threads
+    // were two and a half rounds: 15 us per launch at 128 sequences).
+    const bool many = (long)B * H > 1024;
     switch (dec_self_attn_bucket(max_keys)) {
-        case 0: launch_self_attn_rpt<1>(q, kc, vc, out, B, H, Tctx, st, s, src_rows); break;
-        case 1: launch_self_attn_rpt<2>(q, kc, vc, out, B, H, Tctx, st, s, src_rows); break;
-        case 2: launch_self_attn_rpt<4>(q, kc, vc, out, B, H, Tctx, st, s, src_rows); break;
-        default: launch_self_attn_rpt<7>(q, kc, vc, out, B, H, Tctx, st, s, src_rows); break;   // 448 positions
+        case 0: if (many) launch_self_attn_rpt<128, 4>(q, kc, vc, out, B, H, Tctx, st, s, src_rows);
+                else launch_self_attn_rpt<512, 1>(q, kc, vc, out, B, H, Tctx, st, s, src_rows);
+                break;
+        case 1: if (many) launch_self_attn_rpt<128, 8>(q, kc, vc, out, B, H, Tctx, st, s, src_rows);
+                else launch_self_attn_rpt<512, 2>(q, kc, vc, out, B, H, Tctx, st, s, src_rows);
+                break;
+        case 2: if (many) launch_self_attn_rpt<256, 8>(q, kc, vc, out, B, H, Tctx, st, s, src_rows);
+                else launch_self_attn_rpt<512, 4>(q, kc, vc, out, B, H, Tctx, st, s, src_rows);
+                break;
+        default: launch_self_attn_rpt<512, 7>(q, kc, vc, out, B, H, Tctx, st, s, src_rows); break;   // 448 positions
     }
 }
 

@@ -17,6 +17,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // registers between the two passes so HBM sees one read and one fp16 write.
 // modeling_whisper.py:392,402,642 (nn.LayerNorm defaults).
 constexpr int LN_MAXV = 8;     // D <= 2048
+template <int NV>               // NV = ceil(D / 256): float4 pieces per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, f16* __restrict__ y,
                                                         float* __restrict__ y32, int rows, int D,
@@ -28,20 +29,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (advance && blockIdx.x == 0 && threadIdx.x == 0) *advance += 1;
     if (row >= rows) return;
     const float* xr = x + (long)row * D;
-    float4 v[LN_MAXV];
+    // every load of the wave is issued here (row, gain, offset): one round trip, the reductions run behind it
+    float4 v[NV], gg[NV], bb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = min((lane + 64 * i) * 4, D - 4);          // past the row's end: a duplicate of its last piece, never used
+        v[i] = *reinterpret_cast<const float4*>(xr + c);
+        gg[i] = *reinterpret_cast<const float4*>(g + c);
+        bb[i] = *reinterpret_cast<const float4*>(b + c);
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < D) {
-            v[i] = *reinterpret_cast<const float4*>(xr + c);
-            s += v[i].x + v[i].y + v[i].z + v[i].w;
-        }
-    }
+    for (int i = 0; i < NV; ++i)
+        if ((lane + 64 * i) * 4 < D) s += v[i].x + v[i].y + v[i].z + v[i].w;
     const float mean = wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < D) {
             v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
@@ -50,13 +54,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     const float rstd = rsqrtf(wave_sum(q) / D + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < D) {
-            const float4 gg = *reinterpret_cast<const float4*>(g + c);
-            const float4 bb = *reinterpret_cast<const float4*>(b + c);
-            const float o0 = v[i].x * rstd * gg.x + bb.x, o1 = v[i].y * rstd * gg.y + bb.y;
-            const float o2 = v[i].z * rstd * gg.z + bb.z, o3 = v[i].w * rstd * gg.w + bb.w;
+            const float o0 = v[i].x * rstd * gg[i].x + bb[i].x, o1 = v[i].y * rstd * gg[i].y + bb[i].y;
+            const float o2 = v[i].z * rstd * gg[i].z + bb[i].z, o3 = v[i].w * rstd * gg[i].w + bb[i].w;
             if (y) *reinterpret_cast<half4*>(y + (long)row * D + c) = half4{(f16)o0, (f16)o1, (f16)o2, (f16)o3};
             if (y32) *reinterpret_cast<float4*>(y32 + (long)row * D + c) = make_float4(o0, o1, o2, o3);
         }
@@ -393,7 +395,13 @@ __global__ __launch_bounds__(256) void fp8_to_f16_kernel(const uint8_t* __restri
 
 void launch_layernorm(const float* x, const float* g, const float* b, f16* y, float* y32, int rows, int D, hipStream_t s,
                       int* advance) {
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, y32, rows, D, advance);
+    const dim3 grid((rows + 3) / 4), block(256);
+    switch ((D + 255) / 256) {
+#define MW_LN_CASE(NV) case NV: hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, s, x, g, b, y, y32, rows, D, advance); break;
+        MW_LN_CASE(1) MW_LN_CASE(2) MW_LN_CASE(3) MW_LN_CASE(4) MW_LN_CASE(5) MW_LN_CASE(6) MW_LN_CASE(7)
+#undef MW_LN_CASE
+        default: hipLaunchKernelGGL(layernorm_kernel<LN_MAXV>, grid, block, 0, s, x, g, b, y, y32, rows, D, advance); break;
+    }
 }
 
 void launch_layernorm_fp8(const float* x, const float* g, const float* b, uint8_t* y8, float* yscale, float* y32, int rows, int D,

@@ -445,12 +445,20 @@ def test_batches_beyond_32_run_as_groups(weight_format):
         eng.set_decode_options(opts)
         pcm = synth.make_pcm_np(100, 23)
         want = np.concatenate([eng.transcribe_batch(pcm[a:a + 16])[0] for a in range(0, 100, 16)])
-        for n in (33, 64, 100):
+        # passes beyond 32 sequences take other projection kernels (other summation order, LayerNorm as its own
+        # launch: logits differ by ~4e-3, tools/dg_probe.py), so a sequence may part from its batch-of-16 ids at a
+        # near-tie: the first tokens and nearly all sequences must agree, and every pass size must agree with the others
+        def close_enough(got, n):
+            assert (got[:, :3] == want[:n, :3]).all(), n
+            assert (got == want[:n]).all(axis=1).sum() >= n - max(1, n // 16), n
+        big, _ = eng.transcribe_batch(pcm[:100])
+        close_enough(big, 100)
+        for n in (33, 64):
             got, lens = eng.transcribe_batch(pcm[:n])
-            assert (got == want[:n]).all(), n
+            assert (got == big[:n]).all(), n
         eng.set_option("graph", 0)
         got, _ = eng.transcribe_batch(pcm[:50])
-        assert (got == want[:50]).all()
+        assert (got == big[:50]).all()
         eng.set_option("graph", 1)
         # beam search: 9 recordings x 5 beams = 45 sequences (three groups, the last ragged)
         eng.logmel(pcm[:9], want_output=False)
