@@ -40,13 +40,24 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, spec
 MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X dense fp16 MFMA, spec (no sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix (v_mfma_f32_32x32x2_f32: 256 FLOP/cycle/CU x 256 CUs x 2.4 GHz)
 # HBM bytes per launch of the cross-attention decode kernel at batch 16 from the PMC counters
-# (2 x FETCH_SIZE 60315.8 KB + WRITE_SIZE 530 KB, profiles/round1d_pmc_counters_f16.csv); algorithmic bytes are 122.88 MB.
-XATTN_TRAFFIC_BYTES = 2 * 60315.8 * 1024 + 530.0 * 1024
+# (2 x FETCH_SIZE 60335.4 KB + WRITE_SIZE 530 KB, profiles/round2_pmc_counters_f16.csv); algorithmic bytes are 122.88 MB.
+XATTN_TRAFFIC_BYTES = 2 * 60335.4 * 1024 + 530.0 * 1024
 # the same for cross_attn8_kernel (e4m3 cache; algorithmic 65.28 MB), profiles/round1d_pmc_counters_fp8_kv8.csv
 XATTN8_TRAFFIC_BYTES = 2 * 32439.7 * 1024 + 530.0 * 1024
 BATCH = 16
 NEW_TOKENS = 128
 MODEL = "large-v3"
+
+
+def decode_bytes(dims, batch, n_prompt, n_new, layer_weight_bytes=2, kv8=False):
+    """Algorithmic HBM bytes of one greedy loop over `batch` sequences: every step reads the decoder weights once,
+    every sequence's cross K/V once and the self-attention cache up to the position."""
+    D, F, T = dims.d_model, dims.ffn_dim, dims.n_audio_ctx
+    steps = n_prompt + n_new - 1
+    w_bytes = dims.dec_layers * (6 * D * D + 2 * D * F) * layer_weight_bytes + dims.vocab * D * 2
+    ckv_bytes = batch * dims.dec_layers * 2 * T * (D + 4 * dims.n_heads if kv8 else D * 2)
+    self_bytes = sum(batch * dims.dec_layers * 2 * (t + 1) * D * 2 for t in range(steps))
+    return steps * (w_bytes + ckv_bytes) + self_bytes
 
 
 def stage_rooflines(dims, batch, n_prompt, n_new, ms, layer_weight_bytes=2, kv8=False):
@@ -57,11 +68,7 @@ def stage_rooflines(dims, batch, n_prompt, n_new, ms, layer_weight_bytes=2, kv8=
     enc_flop = batch * (2 * 3000 * D * 3 * dims.n_mels + 2 * T * D * 3 * D
                         + dims.enc_layers * (2 * T * (4 * D * D + 2 * D * F) + 4 * T * T * D))
     ckv_flop = batch * 2 * T * D * 2 * D * dims.dec_layers
-    steps = n_prompt + n_new - 1
-    w_bytes = dims.dec_layers * (6 * D * D + 2 * D * F) * layer_weight_bytes + dims.vocab * D * 2
-    ckv_bytes = batch * dims.dec_layers * 2 * T * (D + 4 * dims.n_heads if kv8 else D * 2)
-    self_bytes = sum(batch * dims.dec_layers * 2 * (t + 1) * D * 2 for t in range(steps))
-    dec_bytes = steps * (w_bytes + ckv_bytes) + self_bytes
+    dec_bytes = decode_bytes(dims, batch, n_prompt, n_new, layer_weight_bytes, kv8)
 
     def hbm(nbytes, t_ms):
         a = nbytes / (t_ms * 1e-3) / 1e9
@@ -299,6 +306,19 @@ def main(argv=None):
 
     eng.transcribe_batch(pcms[0])               # one step with the GPU to itself: per-stage rooflines
     solo_ms = eng.stage_ms()
+    group_solo = None
+    if grouped:                                 # one decode group with the GPU to itself
+        dec, n_seq = pool.decoders[0], batch * args.group
+        for i in range(args.group):
+            pool.encoders[0].encode_into(pcms[i % len(pcms)], dec, i * batch)
+        dec.set_encoded(n_seq)
+        dec.decode_greedy(n_seq)
+        g_ms = dec.stage_ms()["decode"]
+        g_bytes = decode_bytes(dims, n_seq, len(opts.prompt), NEW_TOKENS, 1 if args.weights == "fp8" else 2, args.kv == "fp8")
+        g_rate = g_bytes / (g_ms * 1e-3) / 1e9
+        group_solo = {"bound": "hbm", "sequences": n_seq, "loop_ms": round(g_ms, 2), "ms_per_16_sequences": round(g_ms * 16 / n_seq, 2),
+                      "achieved": round(g_rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g_rate / HBM_PEAK_GBS, 4),
+                      "note": "the greedy loop of one decode group alone on the GPU; in the timed run several groups and the encoders overlap (whole_run)"}
 
     # dominant kernel: decode-time cross-attention, HIP events on the engine's own stream
     ca_ms, ca_bytes = eng.profile_cross_attention(batch, iters=256)
@@ -335,7 +355,7 @@ def main(argv=None):
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (XATTN_TRAFFIC_BYTES if args.kv == "f16" else XATTN8_TRAFFIC_BYTES) if batch == 16 else None,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/"
-                                           + ("round1d_pmc_counters_f16.csv" if args.kv == "f16" else "round1d_pmc_counters_fp8_kv8.csv"),
+                                           + ("round2_pmc_counters_f16.csv" if args.kv == "f16" else "round1d_pmc_counters_fp8_kv8.csv"),
                          "bytes_per_launch": ca_bytes, "avg_launch_us": round(ca_ms * 1e3, 2)},
         }
         out["roofline_gemv"] = {
@@ -349,6 +369,8 @@ def main(argv=None):
         out["whole_run"] = {"hbm_GBps_per_gpu": round(hb / world, 1), "hbm_frac": round(hb / world / HBM_PEAK_GBS, 4),
                             "mfma_TFLOPs_per_gpu": round(fl / world, 1), "mfma_frac": round(fl / world / MFMA_F16_PEAK_TFLOPS, 4),
                             "step_floor_over_step": round(sr["sum_of_stage_floors_ms"] / (elapsed / args.steps * 1e3), 4)}
+        if group_solo is not None:
+            out["stage_roofline"]["decode_group"] = group_solo
         if grouped:
             out["stage_ms_note"] = "decode: one group's loop (all its steps' sequences); the other stages: one step's 16 chunks"
         if world == 1 and args.also_batch > batch:

@@ -14,7 +14,7 @@ from manual_whisper_amd import synth
 from manual_whisper_amd.decode_options import synthetic_options
 from manual_whisper_amd.engine import Engine
 
-B = 16
+B = int(os.environ.get("MW_B", "16"))      # MW_B=112: the shape of a decode group
 dims = mw.get_dims("large-v3")
 rng = np.random.default_rng(0)
 eng = Engine(dims, 0, B, weight_format=os.environ.get("MW_WEIGHTS", "f16"), kv_format=os.environ.get("MW_KV", "f16"))
