@@ -42,6 +42,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix (v_mfma_f32_32x32x2_f32: 2
 # HBM bytes per launch of the cross-attention decode kernel at batch 16 from the PMC counters
 # (2 x FETCH_SIZE 60335.4 KB + WRITE_SIZE 530 KB, profiles/round2_pmc_counters_f16.csv); algorithmic bytes are 122.88 MB.
 XATTN_TRAFFIC_BYTES = 2 * 60335.4 * 1024 + 530.0 * 1024
+# the same at 112 sequences, the shape of a decode group (algorithmic 860.16 MB), profiles/round2_pmc_counters_f16_b112.csv
+XATTN_TRAFFIC_BYTES_112 = 2 * 422226.5 * 1024 + 3710.0 * 1024
 # the same for cross_attn8_kernel (e4m3 cache; algorithmic 65.28 MB), profiles/round1d_pmc_counters_fp8_kv8.csv
 XATTN8_TRAFFIC_BYTES = 2 * 32439.7 * 1024 + 530.0 * 1024
 BATCH = 16
@@ -320,8 +322,13 @@ def main(argv=None):
                       "achieved": round(g_rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g_rate / HBM_PEAK_GBS, 4),
                       "note": "the greedy loop of one decode group alone on the GPU; in the timed run several groups and the encoders overlap (whole_run)"}
 
-    # dominant kernel: decode-time cross-attention, HIP events on the engine's own stream
-    ca_ms, ca_bytes = eng.profile_cross_attention(batch, iters=256)
+    # dominant kernel: decode-time cross-attention, HIP events on the engine's own stream; at the number of
+    # sequences it runs on in the timed region (a decode group), and at one step's 16 beside it
+    ca16_ms, ca16_bytes = eng.profile_cross_attention(batch, iters=256)
+    ca_ms, ca_bytes, ca_seqs = ca16_ms, ca16_bytes, batch
+    if grouped:
+        ca_seqs = batch * args.group
+        ca_ms, ca_bytes = pool.decoders[0].profile_cross_attention(ca_seqs, iters=128)
     achieved = ca_bytes / (ca_ms * 1e-3) / 1e9
     # the six weight-streaming projections of a decoder layer, back to back as in a step (launch boundaries included)
     gv_ms, gv_bytes = eng.profile_decode_gemvs(batch, iters=256)
@@ -353,11 +360,17 @@ def main(argv=None):
             "roofline": {"kernel": ("dec_attn_kernel<256,12,4>" if args.kv == "f16" else "cross_attn8_kernel<256,12,4>")
                                    + " (decode cross-attention, one launch per layer per token)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (XATTN_TRAFFIC_BYTES if args.kv == "f16" else XATTN8_TRAFFIC_BYTES) if batch == 16 else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "sequences": ca_seqs,
+                         "traffic": ((XATTN_TRAFFIC_BYTES if args.kv == "f16" else XATTN8_TRAFFIC_BYTES) if ca_seqs == 16 else
+                                     XATTN_TRAFFIC_BYTES_112 if (ca_seqs == 112 and args.kv == "f16") else None),
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/"
-                                           + ("round2_pmc_counters_f16.csv" if args.kv == "f16" else "round1d_pmc_counters_fp8_kv8.csv"),
+                                           + (("round2_pmc_counters_f16_b112.csv" if ca_seqs == 112 else "round2_pmc_counters_f16.csv") if args.kv == "f16" else "round1d_pmc_counters_fp8_kv8.csv"),
                          "bytes_per_launch": ca_bytes, "avg_launch_us": round(ca_ms * 1e3, 2)},
         }
+        if grouped:
+            a16 = ca16_bytes / (ca16_ms * 1e-3) / 1e9
+            out["roofline"]["at_16_sequences"] = {"achieved": round(a16, 1), "frac": round(a16 / HBM_PEAK_GBS, 4), "bytes_per_launch": ca16_bytes,
+                                                  "avg_launch_us": round(ca16_ms * 1e3, 2)}
         out["roofline_gemv"] = {
             "kernels": "the six projection launches of a decoder layer (gemv_kernel x5, gemv_splitk_kernel), one token, back to back",
             "bound": "hbm", "achieved": round(gv_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gv_achieved / HBM_PEAK_GBS, 4),
