@@ -231,6 +231,51 @@ int mw_set_option(mw_ctx* ctx, const char* key, int value);
 
 int mw_synchronize(mw_ctx* ctx);
 
+/* ------------------------------------------------------------------------------------------------
+ * Forced alignment: the acoustic model behind whisperx.load_align_model / whisperx.align
+ * (reference transcribe.py:127-135; for language "zh" whisperx loads a Hugging Face Wav2Vec2ForCTC checkpoint of
+ * the wav2vec2-large-xlsr-53 family: layer-norm feature extractor with convolution biases, stable-layer-norm
+ * transformer).  The library computes the frame-wise log-probabilities over the character vocabulary; the
+ * trellis search over them is host code above this boundary.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mw_aligner mw_aligner;
+
+typedef struct {
+    int32_t n_conv;             /* layers of the feature extractor (7)                              */
+    int32_t conv_dim;           /* channels of every layer (512); a multiple of 64, at most 512     */
+    int32_t conv_kernel[8];     /* (10, 3, 3, 3, 3, 2, 2)                                           */
+    int32_t conv_stride[8];     /* (5, 2, 2, 2, 2, 2, 2): one frame per 320 samples                 */
+    int32_t hidden;             /* 1024; n_heads * 64                                               */
+    int32_t n_heads;            /* 16                                                               */
+    int32_t n_layers;           /* 24                                                               */
+    int32_t ffn_dim;            /* 4096                                                             */
+    int32_t pos_kernel;         /* 128: taps of the positional convolution                          */
+    int32_t pos_groups;         /* 16                                                               */
+    int32_t vocab;              /* rows of lm_head                                                  */
+    int32_t max_samples;        /* longest waveform one mw_align_emissions call takes (<= 960000)   */
+} mw_align_desc;
+
+/* Frames the feature extractor makes of n_samples samples (valid convolutions). */
+int64_t mw_align_frames(const mw_align_desc* desc, int64_t n_samples);
+
+/* Create / destroy an aligner on `device`.  mw_align_last_error(NULL) describes a failed mw_align_create on this thread. */
+int mw_align_create(const mw_align_desc* desc, int device, mw_aligner** out);
+void mw_align_destroy(mw_aligner* a);
+const char* mw_align_last_error(const mw_aligner* a);
+
+/* Hand over one tensor of the checkpoint under its Hugging Face state-dict name ("wav2vec2.feature_extractor.
+ * conv_layers.0.conv.weight", ..., "lm_head.bias"), host or device memory, shape as stored.  The positional
+ * convolution is taken either as "....pos_conv_embed.conv.weight" or as its weight-norm pair ("weight_g"/"weight_v"
+ * or "parametrizations.weight.original0"/"original1").  mw_align_finalize checks that every tensor arrived with the
+ * shape the description implies, converts them and frees the staging copies. */
+int mw_align_set_weight(mw_aligner* a, const char* name, const void* data, const int64_t* shape, int ndim, int dtype);
+int mw_align_finalize(mw_aligner* a);
+
+/* pcm: n_samples float32 mono 16 kHz samples (host or device; the caller normalises them if the checkpoint's
+ * feature extractor asks for it) -> out: float32 [n_frames][vocab] log-softmax of the CTC logits (host or device,
+ * room for mw_align_frames(desc, n_samples) rows), *n_frames rows written.  Blocks until out is complete. */
+int mw_align_emissions(mw_aligner* a, const float* pcm, int64_t n_samples, float* out, int32_t* n_frames);
+
 #ifdef __cplusplus
 }
 #endif

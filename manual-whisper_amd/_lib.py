@@ -16,6 +16,8 @@ SYMBOLS = (
     "mw_create", "mw_fork", "mw_fork_sized", "mw_set_weight", "mw_finalize", "mw_set_decode_opts", "mw_destroy", "mw_last_error",
     "mw_logmel", "mw_logmel_noalloc", "mw_encode", "mw_encode_into", "mw_set_encoded", "mw_decode_greedy", "mw_decode_beam", "mw_decode_forced", "mw_transcribe_batch",
     "mw_frame_energy_db", "mw_stage_ms", "mw_profile_cross_attention", "mw_profile_decode_gemvs", "mw_set_option", "mw_synchronize",
+    "mw_align_frames", "mw_align_create", "mw_align_destroy", "mw_align_last_error", "mw_align_set_weight", "mw_align_finalize",
+    "mw_align_emissions",
 )
 
 
@@ -33,6 +35,12 @@ class DecodeOpts(C.Structure):
                 ("suppress", C.POINTER(C.c_int32)), ("n_suppress", C.c_int32),
                 ("begin_suppress", C.POINTER(C.c_int32)), ("n_begin_suppress", C.c_int32),
                 ("eot", C.c_int32), ("max_new", C.c_int32)]
+
+
+class AlignDesc(C.Structure):
+    _fields_ = [("n_conv", C.c_int32), ("conv_dim", C.c_int32), ("conv_kernel", C.c_int32 * 8), ("conv_stride", C.c_int32 * 8),
+                ("hidden", C.c_int32), ("n_heads", C.c_int32), ("n_layers", C.c_int32), ("ffn_dim", C.c_int32),
+                ("pos_kernel", C.c_int32), ("pos_groups", C.c_int32), ("vocab", C.c_int32), ("max_samples", C.c_int32)]
 
 
 _lib = None
@@ -96,8 +104,18 @@ def load() -> C.CDLL:
     lib.mw_profile_decode_gemvs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
     lib.mw_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.mw_synchronize.argtypes = [vp]
+    lib.mw_align_frames.argtypes = [C.POINTER(AlignDesc), C.c_int64]
+    lib.mw_align_frames.restype = C.c_int64
+    lib.mw_align_create.argtypes = [C.POINTER(AlignDesc), C.c_int, C.POINTER(vp)]
+    lib.mw_align_destroy.argtypes = [vp]
+    lib.mw_align_destroy.restype = None
+    lib.mw_align_last_error.argtypes = [vp]
+    lib.mw_align_last_error.restype = C.c_char_p
+    lib.mw_align_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int, C.c_int]
+    lib.mw_align_finalize.argtypes = [vp]
+    lib.mw_align_emissions.argtypes = [vp, f32p, C.c_int64, f32p, C.POINTER(C.c_int32)]
     for name in SYMBOLS:
-        if name not in ("mw_destroy", "mw_last_error"):
+        if name not in ("mw_destroy", "mw_last_error", "mw_align_destroy", "mw_align_last_error", "mw_align_frames"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

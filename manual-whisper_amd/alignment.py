@@ -1,0 +1,428 @@
+"""Forced alignment: ``load_align_model`` / ``align``, the two whisperx calls of reference transcribe.py:127-135.
+
+    model_a, metadata = whisperx.load_align_model(language_code="zh", device=device, model_name=None)
+    result_aligned = whisperx.align(result["segments"], model_a, metadata, audio, device)
+
+For "zh" whisperx resolves ``model_name=None`` to a Hugging Face ``Wav2Vec2ForCTC`` checkpoint of the
+wav2vec2-large-xlsr-53 family.  Here the acoustic model runs in libmwhip.so (``mw_align_emissions``: raw
+waveform -> frame-wise log-probabilities over the character vocabulary); this module is the host logic around it,
+restated from whisperx's alignment.py as published (3.x: characters outside the vocabulary align as a wildcard,
+trellis over (frames, tokens), backtracking, repeats merged into character segments, characters gathered into
+words and sentences, missing times filled from the nearest neighbour).  Recent whisperx releases walk the trellis
+back with a beam of width 2 instead of the plain walk; how that beam ranks its partial paths could not be checked
+offline, so the plain walk, which returns the trellis optimum, is what runs here.
+
+whisperx is not in the reference tree and cannot be installed here, the reference holds no alignment vectors, and
+nltk's Punkt sentence tokenizer (which whisperx uses to cut a segment into sentences) is absent too:
+PARITY WITH WHISPERX IS UNPINNED.  Sentences are cut by the plain rule in ``sentence_spans``.
+
+There is no CPU fallback: without libmwhip.so and a GPU, ``load_align_model`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .dims import SAMPLE_RATE
+from .engine import EngineError, _DTYPES, _ptr
+
+LANGUAGES_WITHOUT_SPACES = ("ja", "zh")
+MAX_ALIGN_SECONDS = 60                    # longest segment one call aligns (mw_align_desc.max_samples)
+MIN_SAMPLES = 400                         # shorter segments are zero-padded to this (one receptive field)
+
+
+# ------------------------------------------------------------------------------------------------
+# the acoustic model
+# ------------------------------------------------------------------------------------------------
+class Aligner:
+    """A wav2vec2 CTC model on one GPU: ``emissions(wave) -> float32 [frames][vocab]`` log-probabilities."""
+
+    def __init__(self, cfg: dict, device: int = 0, max_seconds: int = MAX_ALIGN_SECONDS):
+        if cfg.get("feat_extract_norm", "group") != "layer" or not cfg.get("do_stable_layer_norm", False) or not cfg.get("conv_bias", False):
+            raise EngineError("only the wav2vec2 variant with a layer-norm feature extractor, convolution biases and stable "
+                              "layer norm (wav2vec2-large-xlsr-53 and its fine-tunes) is built")
+        if len(set(cfg["conv_dim"])) != 1:
+            raise EngineError("the feature extractor's layers must share one width")
+        self._lib = _lib.load()
+        self.cfg = cfg
+        self.device = device
+        d = _lib.AlignDesc()
+        d.n_conv, d.conv_dim = len(cfg["conv_dim"]), cfg["conv_dim"][0]
+        for i, (k, s) in enumerate(zip(cfg["conv_kernel"], cfg["conv_stride"])):
+            d.conv_kernel[i], d.conv_stride[i] = k, s
+        d.hidden, d.n_heads, d.n_layers = cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_hidden_layers"]
+        d.ffn_dim = cfg["intermediate_size"]
+        d.pos_kernel, d.pos_groups = cfg["num_conv_pos_embeddings"], cfg["num_conv_pos_embedding_groups"]
+        d.vocab = cfg["vocab_size"]
+        d.max_samples = int(max_seconds) * SAMPLE_RATE
+        self.desc = d
+        h = C.c_void_p()
+        rc = self._lib.mw_align_create(C.byref(d), device, C.byref(h))
+        if rc != 0:
+            raise EngineError(f"mw_align_create failed ({rc}): {self._lib.mw_align_last_error(None).decode()}")
+        self._h = h
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise EngineError(f"{what} failed ({rc}): {self._lib.mw_align_last_error(self._h).decode()}")
+
+    def load_weights(self, weights) -> None:
+        """``weights``: the checkpoint's state dict (Hugging Face names), numpy arrays or torch tensors."""
+        for name, w in weights.items():
+            if "masked_spec_embed" in name or name.startswith(("quantizer.", "project_q.", "project_hid.")):
+                continue                                           # pre-training heads: not part of the CTC forward pass
+            if isinstance(w, np.ndarray):
+                w = np.ascontiguousarray(w)
+                dt, shape = _DTYPES.get(str(w.dtype)), w.shape
+            else:
+                w = w.contiguous()
+                dt, shape = _DTYPES.get(str(w.dtype).replace("torch.", "")), tuple(w.shape)
+            if dt is None:
+                raise EngineError(f"weight {name}: unsupported dtype {w.dtype}")
+            shp = (C.c_int64 * len(shape))(*shape)
+            self._check(self._lib.mw_align_set_weight(self._h, name.encode(), _ptr(w), shp, len(shape), dt), f"mw_align_set_weight({name})")
+        self._check(self._lib.mw_align_finalize(self._h), "mw_align_finalize")
+
+    def n_frames(self, n_samples: int) -> int:
+        return int(self._lib.mw_align_frames(C.byref(self.desc), int(n_samples)))
+
+    def emissions(self, wave) -> np.ndarray:
+        wave = np.ascontiguousarray(wave, dtype=np.float32).reshape(-1)
+        out = np.empty((max(self.n_frames(len(wave)), 1), self.cfg["vocab_size"]), np.float32)
+        n = C.c_int32(0)
+        self._check(self._lib.mw_align_emissions(self._h, _ptr(wave), len(wave), _ptr(out), C.byref(n)), "mw_align_emissions")
+        return out[: n.value]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mw_align_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _load_state_dict(path: str) -> dict:
+    st = os.path.join(path, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.numpy import load_file
+        return load_file(st)
+    pt = os.path.join(path, "pytorch_model.bin")
+    if os.path.exists(pt):
+        import torch
+        return torch.load(pt, map_location="cpu", weights_only=True)
+    raise FileNotFoundError(f"{path}: no model.safetensors or pytorch_model.bin")
+
+
+def load_align_model(language_code: str, device="cuda", model_name: Optional[str] = None, model_dir: Optional[str] = None):
+    """-> (model, metadata), like whisperx.load_align_model (reference transcribe.py:130).
+
+    There is no network: ``model_name`` (or, when it is None, the directory ``MW_ALIGN_MODEL`` names) must be a LOCAL
+    directory in Hugging Face layout (config.json, model.safetensors or pytorch_model.bin, vocab.json); ``model_dir``
+    is joined in front of a relative ``model_name``.  metadata = {"language", "dictionary", "type"} as whisperx returns
+    it, the dictionary being the tokenizer's vocabulary with lower-cased keys."""
+    name = model_name or os.environ.get("MW_ALIGN_MODEL")
+    if not name:
+        raise FileNotFoundError(f"no alignment model for language {language_code!r}: pass model_name=<local directory> or set MW_ALIGN_MODEL "
+                                "(whisperx would download a wav2vec2 checkpoint here; this build has no network)")
+    path = name if os.path.isabs(name) or not model_dir else os.path.join(model_dir, name)
+    with open(os.path.join(path, "config.json"), encoding="utf-8") as f:
+        cfg = json.load(f)
+    with open(os.path.join(path, "vocab.json"), encoding="utf-8") as f:
+        vocab = json.load(f)
+    index = 0
+    if isinstance(device, str) and ":" in device:
+        index = int(device.split(":")[1])
+    elif isinstance(device, int):
+        index = device
+    model = Aligner(cfg, device=index)
+    model.load_weights(_load_state_dict(path))
+    metadata = {"language": language_code, "dictionary": {ch.lower(): int(code) for ch, code in vocab.items()}, "type": "huggingface"}
+    return model, metadata
+
+
+# ------------------------------------------------------------------------------------------------
+# alignment of a token sequence to the emissions
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Point:
+    token_index: int
+    time_index: int
+    score: float
+
+
+@dataclass
+class Segment:
+    label: str
+    start: int
+    end: int
+    score: float
+
+    @property
+    def length(self) -> int:
+        return self.end - self.start
+
+
+def wildcard_emission(frame: np.ndarray, tokens: Sequence[int], blank_id: int) -> np.ndarray:
+    """Log-probability of each token in one frame; a wildcard (-1, a character outside the vocabulary) scores
+    the best non-blank entry of the frame."""
+    tok = np.asarray(tokens, np.int64)
+    wild = tok == -1
+    regular = frame[np.where(wild, 0, tok)]
+    if not wild.any():
+        return regular
+    masked = frame.copy()
+    masked[blank_id] = -np.inf
+    return np.where(wild, masked.max(), regular)
+
+
+def get_trellis(emission: np.ndarray, tokens: Sequence[int], blank_id: int = 0) -> np.ndarray:
+    """trellis[t][j]: best log-probability of frames [0, t) with the path standing on token j at frame t.
+    Token 0 holds from frame 0 (its column sums blanks), a move j-1 -> j at frame t pays token j's emission."""
+    emission = np.asarray(emission, np.float32)
+    T, J = emission.shape[0], len(tokens)
+    trellis = np.zeros((T, J), np.float32)
+    trellis[1:, 0] = np.cumsum(emission[1:, blank_id], dtype=np.float32)
+    trellis[0, 1:] = -np.inf
+    if J > 1:
+        trellis[-J + 1:, 0] = np.inf
+    for t in range(T - 1):
+        trellis[t + 1, 1:] = np.maximum(trellis[t, 1:] + emission[t, blank_id],
+                                        trellis[t, :-1] + wildcard_emission(emission[t], tokens[1:], blank_id))
+    return trellis
+
+
+def backtrack(trellis: np.ndarray, emission: np.ndarray, tokens: Sequence[int], blank_id: int = 0) -> Optional[List[Point]]:
+    """The most likely path, walked back greedily from the last frame and the last token."""
+    t, j = trellis.shape[0] - 1, trellis.shape[1] - 1
+    path = [Point(j, t, float(np.exp(emission[t, blank_id])))]
+    while j > 0:
+        if t <= 0:
+            return None
+        p_stay = emission[t - 1, blank_id]
+        p_change = wildcard_emission(emission[t - 1], [tokens[j]], blank_id)[0]
+        stayed = trellis[t - 1, j] + p_stay
+        changed = trellis[t - 1, j - 1] + p_change
+        t -= 1
+        if changed > stayed:
+            j -= 1
+        path.append(Point(j, t, float(np.exp(p_change if changed > stayed else p_stay))))
+    while t > 0:
+        path.append(Point(j, t - 1, float(np.exp(emission[t - 1, blank_id]))))
+        t -= 1
+    return path[::-1]
+
+
+def merge_repeats(path: Sequence[Point], transcript: str) -> List[Segment]:
+    """Runs of one token index -> one segment [first frame, last frame + 1) scored by the mean point score."""
+    i1, i2, segments = 0, 0, []
+    while i1 < len(path):
+        while i2 < len(path) and path[i1].token_index == path[i2].token_index:
+            i2 += 1
+        score = sum(path[k].score for k in range(i1, i2)) / (i2 - i1)
+        segments.append(Segment(transcript[path[i1].token_index], path[i1].time_index, path[i2 - 1].time_index + 1, score))
+        i1 = i2
+    return segments
+
+
+# ------------------------------------------------------------------------------------------------
+# segments -> aligned segments
+# ------------------------------------------------------------------------------------------------
+def sentence_spans(text: str) -> List[Tuple[int, int]]:
+    """(start, end) of the sentences of `text`: a sentence ends after a run of . ? ! (or their full-width forms)
+    that is followed by white space; the next one starts at the next character that is not white space.
+    (whisperx uses nltk's Punkt tokenizer with a list of abbreviations; this is its basic rule without the
+    learned exceptions.  Text without white space, the usual Chinese output, is one sentence in both.)"""
+    spans, start, i, n = [], None, 0, len(text)
+    while i < n:
+        if start is None:
+            if not text[i].isspace():
+                start = i
+            i += 1
+            continue
+        if text[i] in ".?!。？！" and i + 1 < n and text[i + 1].isspace():
+            spans.append((start, i + 1))
+            start = None
+        i += 1
+    if start is not None:
+        end = len(text.rstrip())
+        spans.append((start, max(end, start + 1)))
+    return spans
+
+
+def _nanmin(vals):
+    vals = [v for v in vals if v is not None and not (isinstance(v, float) and math.isnan(v))]
+    return min(vals) if vals else math.nan
+
+
+def _nanmax(vals):
+    vals = [v for v in vals if v is not None and not (isinstance(v, float) and math.isnan(v))]
+    return max(vals) if vals else math.nan
+
+
+def interpolate_nans(values: Sequence[float], method: str = "nearest") -> List[float]:
+    """Missing entries (NaN) take the value of the nearest known entry (the earlier one on a tie) when at least two
+    entries are known, else the known one everywhere; `method` "linear" interpolates on the index instead.
+    Entries before the first / after the last known one copy it."""
+    v = [math.nan if x is None else float(x) for x in values]
+    known = [i for i, x in enumerate(v) if not math.isnan(x)]
+    if not known:
+        return v
+    out = list(v)
+    for i, x in enumerate(v):
+        if not math.isnan(x):
+            continue
+        left = max((k for k in known if k < i), default=None)
+        right = min((k for k in known if k > i), default=None)
+        if left is None:
+            out[i] = v[right]
+        elif right is None:
+            out[i] = v[left]
+        elif method == "linear":
+            out[i] = v[left] + (v[right] - v[left]) * (i - left) / (right - left)
+        else:
+            out[i] = v[left] if i - left <= right - i else v[right]
+    return out
+
+
+def _prepare(segment: dict, dictionary: Dict[str, int], lang: str) -> dict:
+    text = segment["text"]
+    lead = len(text) - len(text.lstrip())
+    trail = len(text) - len(text.rstrip())
+    clean_char, clean_cdx = [], []
+    for cdx, ch in enumerate(text):
+        c = ch.lower()
+        if lang not in LANGUAGES_WITHOUT_SPACES:
+            c = c.replace(" ", "|")
+        if cdx < lead or cdx > len(text) - trail - 1:
+            continue
+        clean_char.append(c if c in dictionary else "*")      # "*": aligned as a wildcard
+        clean_cdx.append(cdx)
+    return {"clean_char": clean_char, "clean_cdx": clean_cdx, "sentence_spans": sentence_spans(text)}
+
+
+def align(transcript: Sequence[dict], model: Aligner, align_model_metadata: dict, audio, device=None,
+          interpolate_method: str = "nearest", return_char_alignments: bool = False, print_progress: bool = False,
+          combined_progress: bool = False) -> dict:
+    """whisperx.align (reference transcribe.py:131): segments {"text", "start", "end"} ->
+    {"segments": [{"start", "end", "text", "words": [{"word", "start", "end", "score"}], ("chars")}], "word_segments": [...]}.
+
+    Per segment: the characters of its text (outside the vocabulary: wildcard) are aligned to the emissions of
+    audio[start:end]; frame indices become seconds by (end - start) / frames; characters are gathered into words
+    (every character is a word for Chinese and Japanese, else split at spaces) and sentences, each sentence one
+    output segment; sentences with equal times are joined."""
+    if isinstance(audio, str):
+        from .audio import load_audio
+        audio = load_audio(audio)
+    audio = np.asarray(audio, np.float32).reshape(-1)
+    max_duration = len(audio) / SAMPLE_RATE
+    dictionary: Dict[str, int] = align_model_metadata["dictionary"]
+    lang = align_model_metadata["language"]
+    blank_id = 0
+    for ch, code in dictionary.items():
+        if ch in ("[pad]", "<pad>"):
+            blank_id = code
+
+    aligned_segments: List[dict] = []
+    for sdx, segment in enumerate(transcript):
+        prep = _prepare(segment, dictionary, lang)
+        t1, t2, text = segment["start"], segment["end"], segment["text"]
+        fallback = {"start": t1, "end": t2, "text": text, "words": [], "chars": [] if return_char_alignments else None}
+        if print_progress:
+            print(f"Progress: {(sdx + 1) / max(len(transcript), 1) * (50 if combined_progress else 100) + (50 if combined_progress else 0):.2f}%...")
+        if not prep["clean_char"]:
+            print(f'Failed to align segment ("{text}"): no characters in this segment found in model dictionary, resorting to original...')
+            aligned_segments.append(fallback)
+            continue
+        if t1 >= max_duration:
+            print(f'Failed to align segment ("{text}"): original start time longer than audio duration, skipping...')
+            aligned_segments.append(fallback)
+            continue
+        text_clean = "".join(prep["clean_char"])
+        tokens = [dictionary.get(c, -1) for c in text_clean]
+        wave = audio[int(t1 * SAMPLE_RATE): int(t2 * SAMPLE_RATE)]
+        if len(wave) < MIN_SAMPLES:
+            wave = np.pad(wave, (0, MIN_SAMPLES - len(wave)))
+        emission = model.emissions(wave)
+        trellis = get_trellis(emission, tokens, blank_id)
+        path = backtrack(trellis, emission, tokens, blank_id)
+        if path is None:
+            print(f'Failed to align segment ("{text}"): backtrack failed, resorting to original...')
+            aligned_segments.append(fallback)
+            continue
+        char_segments = merge_repeats(path, text_clean)
+        ratio = (t2 - t1) / (trellis.shape[0] - 1) if trellis.shape[0] > 1 else 0.0
+
+        chars = []
+        word_idx = 0
+        pos_of = {cdx: i for i, cdx in enumerate(prep["clean_cdx"])}
+        for cdx, ch in enumerate(text):
+            start = end = score = None
+            i = pos_of.get(cdx)
+            if i is not None and i < len(char_segments):
+                seg = char_segments[i]
+                start, end, score = round(seg.start * ratio + t1, 3), round(seg.end * ratio + t1, 3), round(seg.score, 3)
+            chars.append({"char": ch, "start": start, "end": end, "score": score, "word-idx": word_idx})
+            if lang in LANGUAGES_WITHOUT_SPACES or cdx == len(text) - 1 or text[cdx + 1] == " ":
+                word_idx += 1
+
+        subsegments = []
+        for sstart, send in prep["sentence_spans"]:
+            cur = chars[sstart: send + 1]                       # inclusive of `send`, as whisperx selects them
+            words = []
+            seen = []
+            for c in cur:
+                if c["word-idx"] not in seen:
+                    seen.append(c["word-idx"])
+            for w in seen:
+                wchars = [c for c in cur if c["word-idx"] == w]
+                wtext = "".join(c["char"] for c in wchars).strip()
+                if not wtext:
+                    continue
+                wchars = [c for c in wchars if c["char"] != " "]
+                ws, we = _nanmin(c["start"] for c in wchars), _nanmax(c["end"] for c in wchars)
+                scores = [c["score"] for c in wchars if c["score"] is not None]
+                word = {"word": wtext}
+                if not math.isnan(ws):
+                    word["start"] = ws
+                if not math.isnan(we):
+                    word["end"] = we
+                if scores:
+                    word["score"] = round(sum(scores) / len(scores), 3)
+                words.append(word)
+            sub = {"text": text[sstart:send], "start": _nanmin(c["start"] for c in cur),
+                   "end": _nanmax(c["end"] for c in cur if c["char"] != " "), "words": words}
+            if return_char_alignments:
+                sub["chars"] = [{k: v for k, v in c.items() if k != "word-idx" and v is not None} for c in cur]
+            subsegments.append(sub)
+        starts = interpolate_nans([s["start"] for s in subsegments], interpolate_method)
+        ends = interpolate_nans([s["end"] for s in subsegments], interpolate_method)
+        merged: Dict[Tuple[float, float], dict] = {}
+        joiner = "" if lang in LANGUAGES_WITHOUT_SPACES else " "
+        for s, a, b in zip(subsegments, starts, ends):
+            if math.isnan(a) or math.isnan(b):
+                continue                                        # nothing in the segment got a time
+            key = (a, b)
+            if key in merged:
+                merged[key]["text"] = merged[key]["text"] + joiner + s["text"]
+                merged[key]["words"] = merged[key]["words"] + s["words"]
+                if return_char_alignments:
+                    merged[key]["chars"] = merged[key]["chars"] + s["chars"]
+            else:
+                merged[key] = dict(s, start=a, end=b)
+        aligned_segments += [merged[k] for k in sorted(merged)]
+
+    word_segments: List[dict] = []
+    for seg in aligned_segments:
+        word_segments += seg["words"]
+    return {"segments": aligned_segments, "word_segments": word_segments}

@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmwhip.so")
-SOURCES = ["engine.hip", "kernels_mel.hip", "kernels_gemm.hip", "kernels_enc.hip", "kernels_dec.hip", "kernels_vad.hip"]
+SOURCES = ["engine.hip", "kernels_mel.hip", "kernels_gemm.hip", "kernels_enc.hip", "kernels_dec.hip", "kernels_vad.hip", "kernels_w2v.hip", "aligner.hip"]
 HEADERS = [os.path.join(CSRC, "mw_kernels.h"), os.path.join(os.path.dirname(HERE), "include", "mwhip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

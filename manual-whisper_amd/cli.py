@@ -12,6 +12,8 @@ Environment (reference transcribe.py:30-36 plus this engine's own knobs):
   MW_SEGMENT_FILTER  1: clean up with the web service's rules instead (reference web/api/lib/processor.js:52-113:
                  filler noise dropped, neighbours merged; the JSON gains cleanup_stats and quality_report as in
                  web/api/transcribe.js:239)
+  MW_ALIGN_MODEL local directory of a wav2vec2 CTC checkpoint (Hugging Face layout): when set, segment times are
+                 refined by forced alignment as in reference transcribe.py:127-135 (whisperx would download one)
   HF_TOKEN       accepted for compatibility; diarization is not part of this engine
 Launched under torch.distributed.run, the chunks are sharded over the ranks and rank 0 writes the files.
 """
@@ -88,8 +90,19 @@ def transcribe_audio(audio_file, hf_token=None):
         result = model.transcribe(audio, batch_size=BATCH_SIZE, language="zh")
     dt = time.time() - t
     say(f"   转写耗时: {dt:.1f}s (实时比: {dt/max(audio_duration, 1e-9):.3f}x, {audio_duration/max(dt, 1e-9):.0f} audio-s/s)")
-    say("⚠️ 时间戳对齐与说话人分离不在本引擎范围内：片段时间为语音活动窗口（≤30 秒）的边界。")
     model.close()
+    if os.environ.get("MW_ALIGN_MODEL"):
+        if rank == 0:                       # reference transcribe.py:127-135
+            from .alignment import align, load_align_model
+            t = time.time()
+            say("🎯 对齐时间戳...")
+            model_a, metadata = load_align_model(language_code="zh", device=f"cuda:{local_rank}")
+            aligned = align(result["segments"], model_a, metadata, audio, DEVICE, return_char_alignments=False)
+            model_a.close()
+            result = dict(aligned, language=result.get("language", "zh"))
+            say(f"   对齐耗时: {time.time() - t:.1f}s")
+    else:
+        say("⚠️ 未设置 MW_ALIGN_MODEL，跳过时间戳对齐：片段时间为语音活动窗口（≤30 秒）的边界。说话人分离不在本引擎范围内。")
     say("🧹 清理转写文本...")
     if os.environ.get("MW_SEGMENT_FILTER", "0").strip().lower() in ("1", "true", "yes", "on"):
         done = segment_filter.post_process_segments(result.get("segments", []))

@@ -1,0 +1,377 @@
+// Forced-alignment acoustic model behind the mw_align_* entry points of include/mwhip.h: a wav2vec2 CTC
+// network (Hugging Face Wav2Vec2ForCTC, the layer-norm / stable-layer-norm variant of wav2vec2-large-xlsr-53,
+// which is what whisperx.load_align_model resolves Chinese to; reference transcribe.py:130-131) turned into
+// frame-wise log-probabilities over its character vocabulary.  The trellis search over those emissions is host
+// code (Python: manual-whisper_amd/alignment.py).
+//
+// Only the front end is new: the first convolution on the raw waveform, LayerNorm over fp16 rows, the group-major
+// copy for the positional convolution and the log-softmax (kernels_w2v.hip).  The other six convolutions, the
+// feature projection, the grouped positional convolution, the 24 transformer layers and the CTC head are the
+// encoder's GEMM, LayerNorm and attention kernels: a strided convolution over a time-major [T][C] buffer is a
+// GEMM whose A rows overlap (row t = k * C consecutive halfs starting at frame s * t: lda = s * C < K), and one
+// group of the positional convolution is the same over a group-major copy of the hidden states (lda = D / G).
+#include "../../include/mwhip.h"
+#include "mw_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace mw;
+
+static thread_local std::string g_align_create_error;
+
+namespace {
+
+struct Lin { f16* w = nullptr; float* b = nullptr; };
+struct Norm { float* g = nullptr; float* b = nullptr; };
+struct ConvL { f16* w = nullptr; float* w32 = nullptr; float* b = nullptr; Norm ln; int k = 0, s = 0, cin = 0, cout = 0; };
+struct Layer { Norm ln1, ln2; Lin qkv, out, fc1, fc2; };
+
+}  // namespace
+
+struct mw_aligner {
+    mw_align_desc d{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void*> allocs;
+    bool finalized = false;
+    std::map<std::string, std::vector<float>> host;       // tensors as handed over (float32), until mw_align_finalize
+    std::map<std::string, std::vector<int64_t>> shapes;
+
+    std::vector<ConvL> conv;
+    Norm proj_ln; Lin proj;
+    f16* pos_w = nullptr; float* pos_b = nullptr;          // [G][D/G][K][D/G], [D]
+    std::vector<Layer> layers;
+    Norm enc_ln;
+    Lin head; int vpad = 0;
+
+    // workspaces, sized for max_samples
+    float* pcm = nullptr;
+    f16* h[2] = {nullptr, nullptr};                        // ping-pong conv outputs [T_i][C]
+    float* x = nullptr; f16* xn = nullptr;                 // residual stream [T][D], normalised rows
+    f16* pack = nullptr;                                   // [G][T + K][D/G]
+    f16 *q = nullptr, *k = nullptr, *vT = nullptr, *att = nullptr, *hid = nullptr;
+    float* logits = nullptr;                               // [T][vpad]
+    int max_frames = 0, max_t0 = 0;
+};
+
+#define ACHK(call)                                                                                \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            char buf_[512];                                                                       \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            a->err = buf_;                                                                        \
+            return MW_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+static int afail(mw_aligner* a, int code, const std::string& msg) { a->err = msg; return code; }
+
+template <typename T>
+static int aalloc(mw_aligner* a, T** out, size_t count, bool zero = false) {
+    void* p = nullptr;
+    const size_t bytes = count * sizeof(T) + 256;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { a->err = std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e); return MW_ERR_NOMEM; }
+    a->allocs.push_back(p);
+    if (zero && hipMemset(p, 0, bytes) != hipSuccess) { a->err = "hipMemset failed"; return MW_ERR_HIP; }
+    *out = reinterpret_cast<T*>(p);
+    return MW_OK;
+}
+#define AALLOC(ptr, count, ...) do { int r_ = aalloc(a, &(ptr), (count), ##__VA_ARGS__); if (r_) return r_; } while (0)
+
+static long frames_after(const mw_align_desc& d, long n, int upto) {
+    for (int i = 0; i < upto; ++i) n = n < d.conv_kernel[i] ? 0 : (n - d.conv_kernel[i]) / d.conv_stride[i] + 1;
+    return n;
+}
+
+extern "C" int64_t mw_align_frames(const mw_align_desc* desc, int64_t n_samples) {
+    if (!desc || n_samples < 0) return 0;
+    return frames_after(*desc, n_samples, desc->n_conv);
+}
+
+extern "C" int mw_align_create(const mw_align_desc* desc, int device, mw_aligner** out) {
+    if (!desc || !out) { g_align_create_error = "mw_align_create: null argument"; return MW_ERR_ARG; }
+    *out = nullptr;
+    const mw_align_desc& d = *desc;
+    auto bad = [&](const char* m) { g_align_create_error = std::string("mw_align_create: ") + m; return MW_ERR_ARG; };
+    if (d.n_conv < 2 || d.n_conv > 8) return bad("n_conv must be in 2..8");
+    if (d.conv_dim < 64 || d.conv_dim % 64 || d.conv_dim > 512) return bad("conv_dim must be a multiple of 64, at most 512");
+    if (d.conv_kernel[0] < 1 || d.conv_kernel[0] > 16) return bad("the first convolution's kernel must be in 1..16");
+    for (int i = 0; i < d.n_conv; ++i) if (d.conv_kernel[i] < 1 || d.conv_stride[i] < 1) return bad("bad convolution kernel / stride");
+    if (d.hidden <= 0 || d.n_heads <= 0 || d.hidden != d.n_heads * kHeadDim) return bad("head_dim must be 64");
+    if (d.hidden % 64 || d.ffn_dim % 64 || d.hidden > 2048) return bad("hidden and ffn_dim must be multiples of 64, hidden <= 2048");
+    if (d.pos_groups < 1 || d.hidden % d.pos_groups || (d.hidden / d.pos_groups) % 8 || d.pos_kernel < 2 || (d.pos_kernel * (d.hidden / d.pos_groups)) % 64)
+        return bad("positional convolution: hidden / groups must be a multiple of 8 and kernel * hidden / groups a multiple of 64");
+    if (d.n_layers < 1 || d.vocab < 2) return bad("bad layer count / vocabulary");
+    if (d.max_samples < 400 || d.max_samples > 16000 * 60) return bad("max_samples must be in 400 .. 960000");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_align_create_error = "mw_align_create: no such HIP device"; return MW_ERR_HIP; }
+    mw_aligner* a = new mw_aligner();
+    a->d = d; a->device = device;
+    auto bail = [&](int code) { g_align_create_error = a->err; mw_align_destroy(a); return code; };
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) { a->err = "stream creation failed"; return bail(MW_ERR_HIP); }
+    a->max_t0 = (int)frames_after(d, d.max_samples, 1);
+    a->max_frames = (int)frames_after(d, d.max_samples, d.n_conv);
+    a->vpad = (d.vocab + 63) / 64 * 64;
+    auto work = [&]() -> int {
+        const size_t C = d.conv_dim, D = d.hidden, F = d.ffn_dim, T = a->max_frames, H = d.n_heads;
+        const size_t Tpad = (T + 7) / 8 * 8;
+        AALLOC(a->pcm, (size_t)d.max_samples);
+        AALLOC(a->h[0], (size_t)a->max_t0 * C); AALLOC(a->h[1], (size_t)frames_after(d, d.max_samples, 2) * C + C);
+        AALLOC(a->x, T * D); AALLOC(a->xn, T * D);
+        AALLOC(a->pack, (size_t)(T + d.pos_kernel) * D);
+        AALLOC(a->q, T * D); AALLOC(a->k, T * D); AALLOC(a->vT, H * 64 * Tpad, true); AALLOC(a->att, T * D); AALLOC(a->hid, T * F);
+        AALLOC(a->logits, T * (size_t)a->vpad);
+        return MW_OK;
+    };
+    int r = work();
+    if (r) return bail(r);
+    *out = a;
+    return MW_OK;
+}
+
+extern "C" void mw_align_destroy(mw_aligner* a) {
+    if (!a) return;
+    (void)hipSetDevice(a->device);
+    if (a->stream) (void)hipStreamSynchronize(a->stream);
+    for (void* p : a->allocs) (void)hipFree(p);
+    if (a->stream) (void)hipStreamDestroy(a->stream);
+    delete a;
+}
+
+extern "C" const char* mw_align_last_error(const mw_aligner* a) { return a ? a->err.c_str() : g_align_create_error.c_str(); }
+
+extern "C" int mw_align_set_weight(mw_aligner* a, const char* name_c, const void* data, const int64_t* shape, int ndim, int dtype) {
+    if (!a) return MW_ERR_ARG;
+    if (a->finalized) return afail(a, MW_ERR_STATE, "mw_align_set_weight: already finalized");
+    if (!name_c || !data || !shape || ndim < 1 || ndim > 3) return afail(a, MW_ERR_ARG, "mw_align_set_weight: null or bad argument");
+    if (dtype < MW_F32 || dtype > MW_BF16) return afail(a, MW_ERR_ARG, "mw_align_set_weight: dtype must be MW_F32, MW_F16 or MW_BF16");
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { if (shape[i] < 1) return afail(a, MW_ERR_ARG, "mw_align_set_weight: bad shape"); n *= (size_t)shape[i]; }
+    const size_t esz = dtype == MW_F32 ? 4 : 2;
+    std::vector<uint8_t> raw(n * esz);
+    ACHK(hipSetDevice(a->device));
+    ACHK(hipMemcpy(raw.data(), data, raw.size(), hipMemcpyDefault));        // host or device source
+    std::vector<float> f(n);
+    if (dtype == MW_F32) memcpy(f.data(), raw.data(), n * 4);
+    else if (dtype == MW_F16) { const _Float16* s = reinterpret_cast<const _Float16*>(raw.data()); for (size_t i = 0; i < n; ++i) f[i] = (float)s[i]; }
+    else { const uint16_t* s = reinterpret_cast<const uint16_t*>(raw.data()); for (size_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)s[i] << 16; memcpy(&f[i], &u, 4); } }
+    const std::string name(name_c);
+    a->host[name] = std::move(f);
+    a->shapes[name] = std::vector<int64_t>(shape, shape + ndim);
+    return MW_OK;
+}
+
+namespace {
+
+struct Importer {
+    mw_aligner* a;
+    int rc = MW_OK;
+    const std::vector<float>* get(const std::string& name, std::vector<int64_t> want) {
+        if (rc) return nullptr;
+        auto it = a->host.find(name);
+        if (it == a->host.end()) { a->err = "mw_align_finalize: weight '" + name + "' was never set"; rc = MW_ERR_MISSING; return nullptr; }
+        if (a->shapes[name] != want) { a->err = "mw_align_finalize: wrong shape for '" + name + "'"; rc = MW_ERR_ARG; return nullptr; }
+        return &it->second;
+    }
+    float* up32(const std::vector<float>& v, size_t padded = 0) {
+        float* p = nullptr;
+        const size_t n = std::max(padded, v.size());
+        if (aalloc(a, &p, n, true) != MW_OK) { rc = MW_ERR_NOMEM; return nullptr; }
+        if (hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { a->err = "weight upload failed"; rc = MW_ERR_HIP; }
+        return p;
+    }
+    f16* up16(const std::vector<_Float16>& v) {
+        f16* p = nullptr;
+        if (aalloc(a, &p, v.size(), true) != MW_OK) { rc = MW_ERR_NOMEM; return nullptr; }
+        if (hipMemcpy(p, v.data(), v.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { a->err = "weight upload failed"; rc = MW_ERR_HIP; }
+        return p;
+    }
+    float* vec(const std::string& name, long n, size_t padded = 0) { auto* v = get(name, {n}); return v ? up32(*v, padded) : nullptr; }
+    f16* mat(const std::string& name, long r, long c, long padded_rows = 0) {
+        auto* v = get(name, {r, c});
+        if (!v) return nullptr;
+        std::vector<_Float16> h((size_t)std::max(r, padded_rows) * c, (_Float16)0.f);
+        for (size_t i = 0; i < v->size(); ++i) h[i] = (_Float16)(*v)[i];
+        return up16(h);
+    }
+    Norm norm(const std::string& prefix, long n) { Norm o; o.g = vec(prefix + ".weight", n); o.b = vec(prefix + ".bias", n); return o; }
+};
+
+}  // namespace
+
+extern "C" int mw_align_finalize(mw_aligner* a) {
+    if (!a) return MW_ERR_ARG;
+    if (a->finalized) return MW_OK;
+    ACHK(hipSetDevice(a->device));
+    const mw_align_desc& d = a->d;
+    const long C = d.conv_dim, D = d.hidden, F = d.ffn_dim, G = d.pos_groups, K = d.pos_kernel, W = D / G;
+    Importer im{a};
+    a->conv.resize(d.n_conv);
+    for (int i = 0; i < d.n_conv; ++i) {
+        ConvL& c = a->conv[i];
+        c.k = d.conv_kernel[i]; c.s = d.conv_stride[i]; c.cin = i == 0 ? 1 : (int)C; c.cout = (int)C;
+        const std::string p = "wav2vec2.feature_extractor.conv_layers." + std::to_string(i);
+        auto* w = im.get(p + ".conv.weight", {C, c.cin, c.k});               // [out][in][k]
+        if (!w) return im.rc;
+        if (i == 0) c.w32 = im.up32(*w);                                     // [C][k] as stored (in = 1)
+        else {                                                               // -> fp16 [out][k][in]: a GEMM row of k * C_in contiguous halfs
+            std::vector<_Float16> h((size_t)C * c.k * C);
+            for (long o = 0; o < C; ++o)
+                for (long ci = 0; ci < C; ++ci)
+                    for (long j = 0; j < c.k; ++j) h[((size_t)o * c.k + j) * C + ci] = (_Float16)(*w)[((size_t)o * C + ci) * c.k + j];
+            c.w = im.up16(h);
+        }
+        c.b = im.vec(p + ".conv.bias", C);
+        c.ln = im.norm(p + ".layer_norm", C);
+        if (i > 0 && (c.k * C) % 64) return afail(a, MW_ERR_ARG, "mw_align_finalize: kernel * conv_dim must be a multiple of 64");
+    }
+    a->proj_ln = im.norm("wav2vec2.feature_projection.layer_norm", C);
+    a->proj.w = im.mat("wav2vec2.feature_projection.projection.weight", D, C);
+    a->proj.b = im.vec("wav2vec2.feature_projection.projection.bias", D);
+    {   // positional convolution: weight norm over dims (0, 1) per tap folded in (modeling_wav2vec2.py:337-355), then
+        // per group g an [W out][K * W in] matrix whose row is (tap, input channel)-major like the group-major copy's rows
+        const std::string p = "wav2vec2.encoder.pos_conv_embed.conv.";
+        std::vector<float> wfull;
+        if (a->host.count(p + "weight")) { auto* w = im.get(p + "weight", {D, W, K}); if (!w) return im.rc; wfull = *w; }
+        else {
+            const bool par = a->host.count(p + "parametrizations.weight.original0") != 0;
+            auto* g = im.get(p + (par ? "parametrizations.weight.original0" : "weight_g"), {1, 1, K});
+            auto* v = im.get(p + (par ? "parametrizations.weight.original1" : "weight_v"), {D, W, K});
+            if (!g || !v) return im.rc;
+            std::vector<double> norm(K, 0.0);
+            for (size_t i = 0; i < v->size(); ++i) norm[i % K] += (double)(*v)[i] * (*v)[i];
+            wfull.resize(v->size());
+            for (size_t i = 0; i < v->size(); ++i) wfull[i] = (float)((double)(*g)[i % K] * (*v)[i] / sqrt(norm[i % K]));
+        }
+        std::vector<_Float16> h((size_t)D * K * W);
+        for (long o = 0; o < D; ++o)
+            for (long ci = 0; ci < W; ++ci)
+                for (long j = 0; j < K; ++j) h[((size_t)o * K + j) * W + ci] = (_Float16)wfull[((size_t)o * W + ci) * K + j];
+        a->pos_w = im.up16(h);
+        a->pos_b = im.vec(p + "bias", D);
+    }
+    a->layers.resize(d.n_layers);
+    for (int i = 0; i < d.n_layers; ++i) {
+        Layer& l = a->layers[i];
+        const std::string p = "wav2vec2.encoder.layers." + std::to_string(i);
+        l.ln1 = im.norm(p + ".layer_norm", D);
+        l.ln2 = im.norm(p + ".final_layer_norm", D);
+        std::vector<_Float16> w((size_t)3 * D * D);
+        std::vector<float> b((size_t)3 * D);
+        int sec = 0;
+        for (const char* pj : {"q_proj", "k_proj", "v_proj"}) {
+            auto* ww = im.get(p + ".attention." + pj + ".weight", {D, D});
+            auto* bb = im.get(p + ".attention." + pj + ".bias", {D});
+            if (!ww || !bb) return im.rc;
+            for (size_t j = 0; j < ww->size(); ++j) w[(size_t)sec * D * D + j] = (_Float16)(*ww)[j];
+            for (long j = 0; j < D; ++j) b[(size_t)sec * D + j] = (*bb)[j];
+            ++sec;
+        }
+        l.qkv.w = im.up16(w); l.qkv.b = im.up32(b);
+        l.out.w = im.mat(p + ".attention.out_proj.weight", D, D); l.out.b = im.vec(p + ".attention.out_proj.bias", D);
+        l.fc1.w = im.mat(p + ".feed_forward.intermediate_dense.weight", F, D); l.fc1.b = im.vec(p + ".feed_forward.intermediate_dense.bias", F);
+        l.fc2.w = im.mat(p + ".feed_forward.output_dense.weight", D, F); l.fc2.b = im.vec(p + ".feed_forward.output_dense.bias", D);
+    }
+    a->enc_ln = im.norm("wav2vec2.encoder.layer_norm", D);
+    a->head.w = im.mat("lm_head.weight", d.vocab, D, a->vpad);             // rows past the vocabulary: zero
+    a->head.b = im.vec("lm_head.bias", d.vocab, a->vpad);
+    if (im.rc) return im.rc;
+    a->host.clear(); a->shapes.clear();
+    a->finalized = true;
+    return MW_OK;
+}
+
+static GemmParams agemm(const f16* A, long lda, const f16* W, long ldw, int M, int N, int K, const float* bias) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.a_rows_per_batch = M > 0 ? M : 1; p.a_batch_stride = 0;
+    p.W = W; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.bias = bias;
+    p.scale = 1.f; p.scale_ncols = 0; p.gelu = 0; p.out_mode = OUT_F16;
+    p.c_rows_per_batch = M > 0 ? M : 1; p.c_batch_stride = 0;
+    return p;
+}
+
+extern "C" int mw_align_emissions(mw_aligner* a, const float* pcm, int64_t n_samples, float* out, int32_t* n_frames) {
+    if (!a) return MW_ERR_ARG;
+    if (!a->finalized) return afail(a, MW_ERR_STATE, "mw_align_emissions: mw_align_finalize has not succeeded yet");
+    if (!pcm || !out || !n_frames) return afail(a, MW_ERR_ARG, "mw_align_emissions: null argument");
+    const mw_align_desc& d = a->d;
+    if (n_samples > d.max_samples) return afail(a, MW_ERR_ARG, "mw_align_emissions: more than max_samples samples (" + std::to_string(d.max_samples) + ")");
+    const int T = (int)frames_after(d, n_samples, d.n_conv);
+    if (T < 1) return afail(a, MW_ERR_ARG, "mw_align_emissions: the input is shorter than one frame of the feature extractor");
+    ACHK(hipSetDevice(a->device));
+    hipStream_t s = a->stream;
+    const int C = d.conv_dim, D = d.hidden, F = d.ffn_dim, H = d.n_heads, G = d.pos_groups, K = d.pos_kernel, W = D / G;
+    ACHK(hipMemcpyAsync(a->pcm, pcm, (size_t)n_samples * 4, hipMemcpyDefault, s));
+    // ---- feature extractor: conv -> LayerNorm over channels -> GELU, seven times
+    int Ti = (int)frames_after(d, n_samples, 1);
+    launch_w2v_conv0(a->pcm, n_samples, a->conv[0].w32, a->conv[0].b, a->conv[0].ln.g, a->conv[0].ln.b, a->h[0], Ti, C, d.conv_kernel[0],
+                     d.conv_stride[0], s);
+    int cur = 0;
+    for (int i = 1; i < d.n_conv; ++i) {
+        const ConvL& c = a->conv[i];
+        const int To = (Ti - c.k) / c.s + 1;
+        GemmParams p = agemm(a->h[cur], (long)c.s * C, c.w, (long)c.k * C, To, C, c.k * C, c.b);
+        p.C = a->h[cur ^ 1]; p.ldc = C;
+        launch_gemm(p, s);
+        launch_ln16(a->h[cur ^ 1], c.ln.g, c.ln.b, To, C, 1e-5f, 1, s);
+        cur ^= 1; Ti = To;
+    }
+    // ---- feature projection: LayerNorm, Linear C -> D into the fp32 residual stream
+    launch_ln16(a->h[cur], a->proj_ln.g, a->proj_ln.b, T, C, 1e-5f, 0, s);
+    ACHK(hipMemsetAsync(a->x, 0, (size_t)T * D * 4, s));
+    {
+        GemmParams p = agemm(a->h[cur], C, a->proj.w, C, T, D, C, a->proj.b);
+        p.out_mode = OUT_RESID_F32; p.C = a->x; p.ldc = D;
+        launch_gemm(p, s);
+    }
+    // ---- x += GELU(grouped positional convolution of x): one GEMM per group over the group-major padded copy
+    launch_w2v_pos_pack(a->x, a->pack, T, D, G, K, s);
+    for (int g = 0; g < G; ++g) {
+        GemmParams p = agemm(a->pack + (size_t)g * (T + K) * W, W, a->pos_w + (size_t)g * W * K * W, (long)K * W, T, W, K * W, a->pos_b + g * W);
+        p.gelu = 1; p.out_mode = OUT_RESID_F32; p.C = a->x + g * W; p.ldc = D;
+        launch_gemm(p, s);
+    }
+    // ---- transformer layers (pre-LayerNorm), then the encoder's final LayerNorm
+    const int Tpad = (T + 7) / 8 * 8;
+    const float qscale = 1.0f / sqrtf((float)kHeadDim);
+    ACHK(hipMemsetAsync(a->vT, 0, (size_t)H * 64 * Tpad * 2, s));
+    for (int li = 0; li < d.n_layers; ++li) {
+        const Layer& l = a->layers[li];
+        launch_layernorm(a->x, l.ln1.g, l.ln1.b, a->xn, nullptr, T, D, s);
+        {
+            GemmParams p = agemm(a->xn, D, l.qkv.w, D, T, 3 * D, D, l.qkv.b);
+            p.scale = qscale; p.scale_ncols = D; p.out_mode = OUT_QKV_SPLIT;
+            p.q = a->q; p.k = a->k; p.v = a->vT; p.T = T; p.Tpad = Tpad; p.H = H; p.D = D;
+            launch_gemm(p, s);
+        }
+        launch_enc_attention(a->q, a->k, a->vT, a->att, 1, H, T, Tpad, s);
+        {   GemmParams p = agemm(a->att, D, l.out.w, D, T, D, D, l.out.b); p.out_mode = OUT_RESID_F32; p.C = a->x; p.ldc = D; launch_gemm(p, s); }
+        launch_layernorm(a->x, l.ln2.g, l.ln2.b, a->xn, nullptr, T, D, s);
+        {   GemmParams p = agemm(a->xn, D, l.fc1.w, D, T, F, D, l.fc1.b); p.gelu = 1; p.C = a->hid; p.ldc = F; launch_gemm(p, s); }
+        {   GemmParams p = agemm(a->hid, F, l.fc2.w, F, T, D, F, l.fc2.b); p.out_mode = OUT_RESID_F32; p.C = a->x; p.ldc = D; launch_gemm(p, s); }
+    }
+    launch_layernorm(a->x, a->enc_ln.g, a->enc_ln.b, a->xn, nullptr, T, D, s);
+    // ---- CTC head and log-softmax over the vocabulary
+    ACHK(hipMemsetAsync(a->logits, 0, (size_t)T * a->vpad * 4, s));
+    {
+        GemmParams p = agemm(a->xn, D, a->head.w, D, T, a->vpad, D, a->head.b);
+        p.out_mode = OUT_RESID_F32; p.C = a->logits; p.ldc = a->vpad;
+        launch_gemm(p, s);
+    }
+    launch_log_softmax_rows(a->logits, T, a->vpad, d.vocab, s);
+    ACHK(hipGetLastError());
+    ACHK(hipMemcpy2DAsync(out, (size_t)d.vocab * 4, a->logits, (size_t)a->vpad * 4, (size_t)d.vocab * 4, T, hipMemcpyDefault, s));
+    ACHK(hipStreamSynchronize(s));
+    *n_frames = T;
+    return MW_OK;
+}

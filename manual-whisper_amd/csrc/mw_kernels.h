@@ -215,4 +215,16 @@ void launch_beam_init(const BeamParams& p, int prompt_len, int max_new, int eot,
 void launch_beam_step(const BeamParams& p, hipStream_t s);
 void launch_dec_finalize(const FinalizeParams& p, int B, hipStream_t s);
 
+// ---------------------------------------------------------------- wav2vec2 front end (forced alignment)
+// First convolution of the feature extractor on the raw waveform, with its LayerNorm over channels and GELU:
+// x float32 [n] -> out fp16 [T0][C], T0 = (n - K0) / S0 + 1.  w [C][K0], b, g, beta [C] float32.  C % 64 == 0, C <= 512, K0 <= 16.
+void launch_w2v_conv0(const float* x, long n, const float* w, const float* b, const float* g, const float* beta, f16* out, int T0, int C,
+                      int K0, int S0, hipStream_t s);
+// LayerNorm over the D channels of fp16 rows, in place, optionally followed by GELU (D % 8 == 0, D <= 4096)
+void launch_ln16(f16* x, const float* g, const float* b, int rows, int D, float eps, int gelu, hipStream_t s);
+// x float32 [T][D] -> pack fp16 [G][T + K][D / G]: group-major copy with K/2 zero rows in front and K - K/2 behind
+void launch_w2v_pos_pack(const float* x, f16* pack, int T, int D, int G, int K, hipStream_t s);
+// rows of z [rows][ld]: z[r][0..V) -= logsumexp(z[r][0..V))
+void launch_log_softmax_rows(float* z, int rows, int ld, int V, hipStream_t s);
+
 }  // namespace mw
