@@ -92,9 +92,9 @@ typedef struct {
 
 /* ---- engine life cycle: whisperx.load_model (reference transcribe.py:107-113) ---- */
 
-/* Create an engine on GPU `device` able to process up to `max_batch` (1..128) chunks per call.  Beyond 32
- * sequences the decode projections run as groups of 32 inside each launch: every weight is streamed from HBM
- * once per step however many groups there are. */
+/* Create an engine on GPU `device` able to process up to `max_batch` (1..512) chunks per call.  Beyond 32
+ * sequences the decode projections take all sequences in one pass over the weights (in blocks of 128 inside a
+ * launch): every weight is streamed from HBM once per step however many sequences there are. */
 int mw_create(const mw_model_desc* desc, int device, int max_batch, mw_ctx** out);
 
 /* Hand over one tensor of a Hugging Face-layout Whisper state dict
@@ -115,7 +115,7 @@ int mw_set_decode_opts(mw_ctx* ctx, const mw_decode_opts* opts);
  * Destroy every fork before its parent.  No counterpart in the reference (single engine). */
 int mw_fork(mw_ctx* parent, mw_ctx** out);
 
-/* mw_fork with a max_batch of its own (1..128): workspaces and caches are sized per context, so a set of
+/* mw_fork with a max_batch of its own (1..512): workspaces and caches are sized per context, so a set of
  * contexts can split roles, e.g. forks of 16 that run the encoder half of passes and forks of 64 that decode
  * what they encoded (mw_encode_into). */
 int mw_fork_sized(mw_ctx* parent, int max_batch, mw_ctx** out);

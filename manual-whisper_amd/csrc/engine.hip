@@ -25,6 +25,7 @@ static thread_local std::string g_create_error;
 // ends; in host code the array's NAME is only a stand-in for it, so the address on each device is asked for
 // once (mw_create, that device current) and only that pointer is ever handed to a kernel.
 constexpr int kNoAllocMaxBatch = 128;
+constexpr int kMaxBatch = 512;                 // sequences one context holds (a decode group of 32 batches of 16)
 constexpr int kMelBlocksPerChunk = (kFrames + 31) / 32;        // 94: the grid of launch_mel_dft
 static __device__ __align__(256) float scratch[kNoAllocMaxBatch * kMelBlocksPerChunk];
 constexpr int kMaxDevices = 64;
@@ -306,7 +307,7 @@ static int alloc_work(mw_ctx* ctx) {
     ALLOC(ctx->xpartial, xrows * H * kXattnSplit * 68); ALLOC(ctx->xtickets, xrows * H, true);
     const size_t seq_groups = (B + 15) / 16;                          // batches beyond 32 run as groups of 16 inside a launch
     ALLOC(ctx->skpartial, splitk_partial_floats(D) * seq_groups); ALLOC(ctx->sktickets, splitk_groups(D) * seq_groups, true);
-    if (B > 32) ALLOC(ctx->dgpartial, decgemm_partial_floats((int)D, (int)F));
+    if (B > 32) ALLOC(ctx->dgpartial, decgemm_partial_floats((int)D, (int)F, (int)B));
     ctx->forced_cap = d.n_text_ctx;
     ALLOC(ctx->forced, B * (size_t)ctx->forced_cap);
     ALLOC(ctx->out_ids, B * (size_t)d.n_text_ctx); ALLOC(ctx->out_len, B); ALLOC(ctx->finished, B);
@@ -321,7 +322,7 @@ extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, m
     if (d.d_model % 32 || d.ffn_dim % 32 || d.d_model > 2048 || d.ffn_dim > 5120) { g_create_error = "mw_create: d_model/ffn_dim must be multiples of 32, d_model <= 2048, ffn_dim <= 5120"; return MW_ERR_ARG; }
     if (d.n_mels % 8 || d.n_mels > 128 || d.n_mels <= 0) { g_create_error = "mw_create: n_mels must be a multiple of 8, <= 128"; return MW_ERR_ARG; }
     if (d.n_audio_ctx != kFrames / 2 || d.n_text_ctx <= 0 || d.n_text_ctx > 448) { g_create_error = "mw_create: n_audio_ctx must be 1500 and n_text_ctx <= 448"; return MW_ERR_ARG; }
-    if (max_batch < 1 || max_batch > 128) { g_create_error = "mw_create: max_batch must be in 1..128"; return MW_ERR_ARG; }
+    if (max_batch < 1 || max_batch > kMaxBatch) { g_create_error = "mw_create: max_batch must be in 1..512"; return MW_ERR_ARG; }
     if (d.vocab < 16 || d.enc_layers < 1 || d.dec_layers < 1) { g_create_error = "mw_create: bad vocab/layer count"; return MW_ERR_ARG; }
     if (d.weight_format != MW_WEIGHTS_F16 && d.weight_format != MW_WEIGHTS_FP8) { g_create_error = "mw_create: weight_format must be MW_WEIGHTS_F16 or MW_WEIGHTS_FP8"; return MW_ERR_ARG; }
     if (d.kv_format != MW_KV_F16 && d.kv_format != MW_KV_FP8) { g_create_error = "mw_create: kv_format must be MW_KV_F16 or MW_KV_FP8"; return MW_ERR_ARG; }
@@ -379,7 +380,7 @@ extern "C" int mw_fork_sized(mw_ctx* parent, int max_batch, mw_ctx** out) {
     *out = nullptr;
     if (!parent->finalized) return fail(parent, MW_ERR_STATE, "mw_fork: the parent must be finalized first");
     if (parent->parent) return fail(parent, MW_ERR_ARG, "mw_fork: fork from the original engine, not from a fork");
-    if (max_batch < 1 || max_batch > 128) return fail(parent, MW_ERR_ARG, "mw_fork_sized: max_batch must be in 1..128");
+    if (max_batch < 1 || max_batch > kMaxBatch) return fail(parent, MW_ERR_ARG, "mw_fork_sized: max_batch must be in 1..512");
     mw_ctx* ctx = new mw_ctx();
     ctx->d = parent->d; ctx->device = parent->device; ctx->max_batch = max_batch;
     ctx->use_graph = parent->use_graph; ctx->check_every = parent->check_every; ctx->use_prefill = parent->use_prefill;
@@ -892,7 +893,7 @@ static void enqueue_layer(mw_ctx* ctx, int li, int B, bool want_logits, const Fi
         p.H = H; p.D = D; p.Tctx = Tc; p.st = ctx->st; p.ln_scratch = ctx->dxn; p.nv = 16;
         p.sk_partial = ctx->skpartial; p.sk_partial_floats = splitk_partial_floats(D);
         p.sk_tickets = ctx->sktickets; p.sk_groups = splitk_groups(D);
-        p.dg_partial = ctx->dgpartial; p.dg_partial_floats = decgemm_partial_floats(D, F); p.dg_groups = splitk_groups(D) * ((ctx->max_batch + 15) / 16);
+        p.dg_partial = ctx->dgpartial; p.dg_partial_floats = decgemm_partial_floats(D, F, ctx->max_batch); p.dg_groups = splitk_groups(D) * ((ctx->max_batch + 15) / 16);
         return p;
     };
     const DecLayerW& l = ctx->dec[li];
@@ -1157,7 +1158,7 @@ extern "C" int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience
     for (int step = first_step; step < n_steps; ++step) {
         if (graph) {
             hipGraphExec_t g;
-            // rows and prompt length in the low word (R <= 128, P <= 448), beam and candidate count in the high one
+            // rows and prompt length in the low word (R <= 512, P <= 448), beam and candidate count in the high one
             int r = ensure_graph(ctx, R, true, fp, ((long)(beam * 64 + max_cand) << 32) | (long)(R * 1024 + P), step + 1, &g, &bp);
             if (r) return r;
             HIPCHK(hipGraphLaunch(g, s));

@@ -499,6 +499,9 @@ __global__ __launch_bounds__(kDecGemmWaves * 64) void gemm_dec_kernel(GemvParams
     static_assert(NW % RT == 0 && MT % MG == 0 && TPW >= 1, "8 waves = RT row tiles x MG sequence groups");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_last;
+    // more than 16*MT sequences: blockIdx.z picks a block of 16*MT of them (its own rows, cache rows, partial slab
+    // and tickets); the blocks of a row group read the same weights at about the same time, so HBM sends them once
+    if (gridDim.z > 1) group_view(p, blockIdx.z, 16 * MT);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
@@ -1570,14 +1573,14 @@ bool launch_splitk(const GemvParams& p, int mt, hipStream_t s) {
 }
 
 
-// gemm_dec_kernel for 33..128 sequences (fp16 input rows).  Row tiles per workgroup: 4 for wide outputs and long K
+// gemm_dec_kernel for more than 32 sequences (fp16 input rows; beyond 128 as blocks of 128 in the grid's z).  Row tiles per workgroup: 4 for wide outputs and long K
 // (fewer passes over the activations), 2 for narrow ones (more row groups); K ranges so that one round of
 // workgroups about fills the CUs and a range fits the registers (KR k-steps) and LDS.  Returns false, having
 // launched nothing, when the shape does not fit (the grouped gemv_kernel takes over).
 template <int MT, int RT, int KR, bool W8>
 void launch_gemm_dec_t(const GemvParams& p, int S, int ks_per, hipStream_t s) {
     constexpr size_t lds = dec_gemm_lds_bytes<MT, KR, W8>();
-    const dim3 grid((p.N + 16 * RT - 1) / (16 * RT), S), block(kDecGemmWaves * 64);
+    const dim3 grid((p.N + 16 * RT - 1) / (16 * RT), S, (p.B + 16 * MT - 1) / (16 * MT)), block(kDecGemmWaves * 64);
     hipLaunchKernelGGL((gemm_dec_kernel<MT, RT, KR, W8>), grid, block, lds, s, p, ks_per);
 }
 
@@ -1594,10 +1597,13 @@ bool launch_gemm_dec_mt(const GemvParams& p, hipStream_t s) {
     S = max(1, S);
     int ks_per = (nks + S - 1) / S;
     S = (nks + ks_per - 1) / ks_per;
-    if (groups > p.dg_groups || (S > 1 && (!p.dg_partial || !p.sk_tickets || (long)groups * S * 16 * rt * 16 * MT > p.dg_partial_floats)))
+    const int blocks = (p.B + 16 * MT - 1) / (16 * MT);                 // sequence blocks (grid z), each with its own slab and tickets
+    const long slab = (long)groups * S * 16 * rt * 16 * MT;
+    if ((long)groups * blocks > p.dg_groups || (S > 1 && (!p.dg_partial || !p.sk_tickets || slab * blocks > p.dg_partial_floats)))
         return false;
     GemvParams q = p;
     q.sk_partial = p.dg_partial;                 // this kernel's own, larger slab; the tickets are shared (always left at zero)
+    q.sk_partial_floats = slab; q.sk_groups = groups;                   // extents of one sequence block (group_view)
 #define MW_DG(RT, KR) launch_gemm_dec_t<MT, RT, KR, W8>(q, S, ks_per, s)
     if (ks_per <= KR_MAX / 2) { if (wide) MW_DG(4, KR_MAX / 2); else MW_DG(2, KR_MAX / 2); }
     else { if (wide) MW_DG(4, KR_MAX); else MW_DG(2, KR_MAX); }
@@ -1616,7 +1622,7 @@ void prepare_gemm_dec_mt() {
 }
 
 bool launch_gemm_dec(const GemvParams& p, hipStream_t s) {
-    if (p.B <= 32 || p.B > 128) return false;
+    if (p.B <= 32) return false;
     if (p.B <= 64) return p.W8 ? launch_gemm_dec_mt<4, true>(p, s) : launch_gemm_dec_mt<4, false>(p, s);
     return p.W8 ? launch_gemm_dec_mt<8, true>(p, s) : launch_gemm_dec_mt<8, false>(p, s);
 }

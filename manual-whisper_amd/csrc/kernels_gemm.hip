@@ -216,6 +216,156 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
     }
 }
 
+// ------------------------------------------------------------------ epilogues of the 256x256 fp16 kernel
+// That kernel files the weight rows of a wave's 64 columns in its LDS slots in a permuted order (see its DMA source
+// setup), so that a lane's accumulators hold EIGHT consecutive columns of a row instead of four:
+//     m = m0 + wr*128 + j*16 + fr,   n = n0 + wc*64 + 32*i2 + 8*fg + [0, 8):  +0..3 in acc[2*i2][j], +4..7 in acc[2*i2 + 1][j]
+// An fp16 result is then one 16-byte store per (i2, j), 16 per lane instead of 32 of 8 bytes: the output burst of a
+// tile is bound by store instructions issued, not by bytes.
+template <int OUT, bool GELU, int SC>
+__device__ __forceinline__ void gemm256_epilogue_perm(const GemmParams& p, float4v (&acc)[4][8], int m0, int n0, int wr, int wc,
+                                                      int fr, int fg) {
+    float4 bv[2][2], wsc[2][2];
+    float sc[2];
+    bool n_ok[2];
+    long col[2];
+    int sec[2];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+        const int n = n0 + wc * 64 + 32 * i2 + 8 * fg;
+        n_ok[i2] = n < p.N;                              // N is a multiple of 8 (checked by the launcher)
+        const int nc = n_ok[i2] ? n : 0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bv[i2][g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (SC > 0) wsc[i2][g] = *reinterpret_cast<const float4*>(p.w_scale + nc + 4 * g);
+        }
+        sc[i2] = n < p.scale_ncols ? p.scale : 1.0f;
+        if constexpr (OUT == OUT_F16 || OUT == OUT_RESID_F32) {
+            col[i2] = nc; sec[i2] = 0;
+        } else {
+            sec[i2] = nc / p.D;
+            const int nn = nc - sec[i2] * p.D;
+            const int hh = nn >> 6, e = nn & 63;
+            if (OUT == OUT_QKV_SPLIT && sec[i2] == 2) col[i2] = ((long)hh * 64 + e) * p.Tpad;     // V^T [B][H][64][Tpad]
+            else col[i2] = (long)hh * p.T * 64 + e;                                              // [B][H][T][64]
+        }
+    }
+    const bool flat = p.c_rows_per_batch >= p.M;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = m0 + wr * 128 + j * 16 + fr;
+        const bool m_ok = m < p.M;
+        long row, rowT = 0;
+        if constexpr (OUT == OUT_F16 || OUT == OUT_RESID_F32) {
+            row = flat ? (long)m * p.ldc : (long)(m / p.c_rows_per_batch) * p.c_batch_stride + (long)(m % p.c_rows_per_batch) * p.ldc;
+        } else {
+            const int bb = m / p.T, tt = m - bb * p.T;
+            row = ((long)bb * p.H * p.T + tt) * 64;
+            rowT = (long)bb * p.H * 64 * p.Tpad + tt;
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            if (!(m_ok && n_ok[i2])) continue;
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4v a = acc[2 * i2 + g][j];
+                const float4 b = bv[i2][g];
+                float w0 = 1.f, w1 = 1.f, w2 = 1.f, w3 = 1.f;
+                if constexpr (SC > 0) { w0 = wsc[i2][g].x; w1 = wsc[i2][g].y; w2 = wsc[i2][g].z; w3 = wsc[i2][g].w; }
+                v[4 * g + 0] = (a[0] * w0 + b.x) * sc[i2]; v[4 * g + 1] = (a[1] * w1 + b.y) * sc[i2];
+                v[4 * g + 2] = (a[2] * w2 + b.z) * sc[i2]; v[4 * g + 3] = (a[3] * w3 + b.w) * sc[i2];
+            }
+            if constexpr (GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+            }
+            if constexpr (OUT == OUT_RESID_F32) {
+                float* c = reinterpret_cast<float*>(p.C) + row + col[i2];
+                float4 o0 = *reinterpret_cast<float4*>(c), o1 = *reinterpret_cast<float4*>(c + 4);
+                o0.x += v[0]; o0.y += v[1]; o0.z += v[2]; o0.w += v[3];
+                o1.x += v[4]; o1.y += v[5]; o1.z += v[6]; o1.w += v[7];
+                *reinterpret_cast<float4*>(c) = o0;
+                *reinterpret_cast<float4*>(c + 4) = o1;
+            } else {
+                const half8 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3], (f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
+                if constexpr (OUT == OUT_F16) {
+                    *reinterpret_cast<half8*>(reinterpret_cast<f16*>(p.C) + row + col[i2]) = h;
+                } else if (OUT == OUT_QKV_SPLIT && sec[i2] == 2) {       // V^T from an untransposed tile: element stores
+                    f16* c = p.v + rowT + col[i2];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) c[(long)e * p.Tpad] = h[e];
+                } else {
+                    f16* base = (OUT == OUT_QKV_SPLIT) ? (sec[i2] == 0 ? p.q : p.k) : (sec[i2] == 0 ? p.k : p.v);
+                    *reinterpret_cast<half8*>(base + row + col[i2]) = h;
+                }
+            }
+        }
+    }
+}
+
+// A V tile of the QKV product computed with the operands' roles exchanged (the kernel feeds weight rows where the
+// activations go and activation rows, permuted as above, where the weights go), so the accumulators hold the
+// TRANSPOSED tile: a lane has eight consecutive frames of one output column,
+//     n = n0 + wr*128 + j*16 + fr,   m = m0 + wc*64 + 32*i2 + 8*fg + [0, 8)
+// and V^T [B][H][64][Tpad] is written with 8-byte stores (frames in fours never straddle a chunk: T % 4 == 0).
+__device__ __forceinline__ void gemm256_epilogue_vT(const GemmParams& p, float4v (&acc)[4][8], int m0, int n0, int wr, int wc, int fr,
+                                                    int fg) {
+    long moff[2][2];
+    bool m_ok[2][2];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int m = m0 + wc * 64 + 32 * i2 + 8 * fg + 4 * g;
+            m_ok[i2][g] = m < p.M;
+            const int mc = m_ok[i2][g] ? m : 0;
+            const int bb = mc / p.T, tt = mc - bb * p.T;
+            moff[i2][g] = (long)bb * p.H * 64 * p.Tpad + tt;
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = n0 + wr * 128 + j * 16 + fr;
+        if (n >= p.N) continue;
+        const float b = p.bias ? p.bias[n] : 0.f;
+        const int nn = n - 2 * p.D;
+        f16* rowp = p.v + (long)nn * p.Tpad;                   // (head * 64 + e) * Tpad, nn = head * 64 + e
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (!m_ok[i2][g]) continue;
+                const float4v a = acc[2 * i2 + g][j];
+                const half4 h = {(f16)(a[0] + b), (f16)(a[1] + b), (f16)(a[2] + b), (f16)(a[3] + b)};
+                *reinterpret_cast<half4*>(rowp + moff[i2][g]) = h;
+            }
+    }
+}
+
+__device__ __forceinline__ void gemm256_epilogue_f16(const GemmParams& p, float4v (&acc)[4][8], int m0, int n0, int wr, int wc, int fr,
+                                                     int fg, bool v_tile) {
+    if (v_tile) { gemm256_epilogue_vT(p, acc, m0, n0, wr, wc, fr, fg); return; }
+    if (p.w_scale) {            // fp16 product over fp8 weight codes expanded to fp16: residual projections, prompt prefill
+        if (p.out_mode == OUT_RESID_F32) gemm256_epilogue_perm<OUT_RESID_F32, false, 1>(p, acc, m0, n0, wr, wc, fr, fg);
+        else if (p.gelu) gemm256_epilogue_perm<OUT_F16, true, 1>(p, acc, m0, n0, wr, wc, fr, fg);
+        else gemm256_epilogue_perm<OUT_F16, false, 1>(p, acc, m0, n0, wr, wc, fr, fg);
+        return;
+    }
+    switch (p.out_mode) {
+        case OUT_F16:
+            if (p.gelu) gemm256_epilogue_perm<OUT_F16, true, 0>(p, acc, m0, n0, wr, wc, fr, fg);
+            else gemm256_epilogue_perm<OUT_F16, false, 0>(p, acc, m0, n0, wr, wc, fr, fg);
+            break;
+        case OUT_RESID_F32:
+            if (p.gelu) gemm256_epilogue_perm<OUT_RESID_F32, true, 0>(p, acc, m0, n0, wr, wc, fr, fg);
+            else gemm256_epilogue_perm<OUT_RESID_F32, false, 0>(p, acc, m0, n0, wr, wc, fr, fg);
+            break;
+        case OUT_QKV_SPLIT: gemm256_epilogue_perm<OUT_QKV_SPLIT, false, 0>(p, acc, m0, n0, wr, wc, fr, fg); break;
+        default: gemm256_epilogue_perm<OUT_KV_SPLIT, false, 0>(p, acc, m0, n0, wr, wc, fr, fg); break;
+    }
+}
+
 template <int MI, bool GLDS, bool F8 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     constexpr int BM = MI * 32;
@@ -412,6 +562,13 @@ __device__ __forceinline__ void wait_vm() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#ifdef MW_GEMM_STAMPS                // timing experiments only: s_memrealtime (100 MHz) at four points of every workgroup
+__device__ unsigned long long g_gemm_stamps[8192 * 4];
+#define MW_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_stamps[blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MW_STAMP(k) do { } while (0)
+#endif
+
 template <bool F8>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) f16 lds[];   // [2 K-tiles][4 half-tiles][128][64], the only LDS object
@@ -435,6 +592,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int gsz = min(GROUP_M, nt_m - gm0);
     const int in_group = bid - group * per_group;
     const int m0 = (gm0 + in_group % gsz) * 256, n0 = (in_group / gsz) * 256;
+    // a tile that lies entirely in the V third of a QKV product is computed transposed (workgroup-uniform)
+    const bool v_tile = !F8 && p.out_mode == OUT_QKV_SPLIT && n0 >= 2 * p.D && p.D % 256 == 0 && p.T % 4 == 0;
 
     // per-lane DMA sources: instruction i of a half-tile fills slot rows (wave*2+i)*8 + (lane>>3).
     // f16 form: 64-bit pointers through the builtin.  fp8 form: the 8-register MFMA operands leave no room for
@@ -454,16 +613,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         a_off0b = (unsigned)(((long)(m0 + (r >> 6) * 128 + (r & 63)) * p.lda + chunk * 8) * 2);
         b_off0b = (unsigned)(((long)(n0 + (r >> 5) * 64 + (r & 31)) * p.ldw + chunk * 8) * 2);
     } else {
+        // Slot row r of an A half-tile holds tile row (r>>6)*128 + h*64 + (r&63).  Slot row r of a B half-tile holds,
+        // of its wave column's 32 rows, row 8*(x>>2) + 4*i + (x&3) where i = (r>>4)&1 is the MFMA subtile and x = r&15 the
+        // operand row inside it: output column 4*fg + c of subtile i is then tile column 8*fg + 4*i + c, and a lane's two
+        // subtiles are eight consecutive columns (gemm256_epilogue_perm).  In a V tile the roles are exchanged: weight
+        // rows fill the A slots and (permuted) activation rows the B slots, which computes the transposed tile.
+        auto act_row = [&](int m) {
+            m = min(m, p.M - 1);
+            return p.A + (long)(m / p.a_rows_per_batch) * p.a_batch_stride + (long)(m % p.a_rows_per_batch) * p.lda;
+        };
+        auto w_row = [&](int n) { return p.W + (long)min(n, p.N - 1) * p.ldw; };
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = (wave * 2 + i) * 8 + (lane >> 3);
                 const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-                const int m = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
-                a_src[h][i] = p.A + (long)(m / p.a_rows_per_batch) * p.a_batch_stride + (long)(m % p.a_rows_per_batch) * p.lda + chunk * 8;
-                const int n = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
-                b_src[h][i] = p.W + (long)n * p.ldw + chunk * 8;
+                const int ar = (r >> 6) * 128 + h * 64 + (r & 63);
+                const int x = r & 15;
+                const int br = (r >> 5) * 64 + h * 32 + 8 * (x >> 2) + 4 * ((r >> 4) & 1) + (x & 3);
+                a_src[h][i] = (v_tile ? w_row(n0 + ar) : act_row(m0 + ar)) + chunk * 8;
+                b_src[h][i] = (v_tile ? act_row(m0 + br) : w_row(n0 + br)) + chunk * 8;
             }
     }
     const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) f16*)lds;
@@ -579,11 +749,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     };
 
     const int nk = p.K / BK;                         // even and >= 2 (checked by the launcher)
+    MW_STAMP(0);
     issue(0, SLOT_A0, true, 0, 0); issue(0, SLOT_B0, false, 0, 0);
     issue(0, SLOT_B1, false, 1, 0); issue(0, SLOT_A1, true, 1, 0);
     issue(1, SLOT_A0, true, 0, 1); issue(1, SLOT_B0, false, 0, 1);
     wait_vm<8>();                                    // A0, B0 of tile 0 have landed
     __builtin_amdgcn_s_barrier();
+    MW_STAMP(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();       // second wave row runs one barrier behind
     for (int t = 0; t < nk - 2; t += 2) {
         ktile(I0{}, I0{}, t);
@@ -592,7 +764,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     ktile(I0{}, I1{}, nk - 2);
     ktile(I1{}, std::integral_constant<int, 2>{}, nk - 1);
     if (wr == 0) __builtin_amdgcn_s_barrier();       // same barrier count for every wave
-    gemm_epilogue<8, F8>(p, acc, m0, n0, wr, wc, fr, fg);
+#ifdef MW_GEMM_SKIP_EPILOGUE          // timing experiments only: the main loop alone (the test is false at run time)
+    if (p.scale != 12345.f) return;
+#endif
+    MW_STAMP(2);
+    if constexpr (F8) gemm_epilogue<8, true>(p, acc, m0, n0, wr, wc, fr, fg);
+    else gemm256_epilogue_f16(p, acc, m0, n0, wr, wc, fr, fg, v_tile);
+#ifdef MW_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MW_STAMP(3);
+#endif
 }
 
 template <bool F8>
@@ -607,6 +788,10 @@ void launch_256(const GemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef MW_GEMM_STAMPS
+void gemm_debug_stamps(unsigned long long* dst, int n) { (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_stamps), (size_t)n * 8); }
+#endif
 
 void launch_gemm(const GemmParams& p0, hipStream_t s) {
     if (p0.f8) {
@@ -632,7 +817,7 @@ void launch_gemm(const GemmParams& p0, hipStream_t s) {
     const int nk = p.K / BK;
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (p.K % BK != 0) launch_t<4, false>(p, s);
-    else if (!no256 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256) launch_256<false>(p, s);
+    else if (!no256 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256 && p.N % 8 == 0) launch_256<false>(p, s);
     else launch_t<4, true>(p, s);
 }
 

@@ -131,8 +131,8 @@ struct GemvParams {
     // all) and the number of row groups the ticket array covers; it shares sk_tickets
     float* dg_partial; long dg_partial_floats; int dg_groups;
 };
-// floats of partial-tile scratch that cover every projection of a model (d_model D, MLP width F) at up to 128 sequences
-inline long decgemm_partial_floats(int D, int F) { return (long)(3 * D > F ? 3 * D : F) * 128 * 8; }
+// floats of partial-tile scratch that cover every projection of a model (d_model D, MLP width F) at up to B sequences
+inline long decgemm_partial_floats(int D, int F, int B = 128) { return (long)(3 * D > F ? 3 * D : F) * 128 * 8 * ((B + 127) / 128); }
 // floats / ints of split-K scratch that cover every residual projection of a model of width D
 inline long splitk_partial_floats(int D) { return (long)(D / 16) * 8 * 2 * 256; }
 inline int splitk_groups(int D) { return D / 16; }

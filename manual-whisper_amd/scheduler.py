@@ -103,8 +103,8 @@ class GroupedPool:
     def __init__(self, engine, batch: int = 16, group: int = 4, n_encoders: int = 2, n_decoders: int = 2):
         if batch < 1 or group < 1 or n_encoders < 1 or n_decoders < 1:
             raise ValueError("batch, group, n_encoders and n_decoders must be >= 1")
-        if batch * group > 128:
-            raise ValueError("a decode group holds at most 128 sequences")
+        if batch * group > 512:
+            raise ValueError("a decode group holds at most 512 sequences")
         self.batch, self.group = int(batch), int(group)
         self.root = engine
         # the engine that owns the weights serves as the first encoder when its own workspaces are large enough

@@ -460,6 +460,20 @@ def test_batches_beyond_32_run_as_groups(weight_format):
         got, _ = eng.transcribe_batch(pcm[:50])
         assert (got == big[:50]).all()
         eng.set_option("graph", 1)
+        # beyond 128 sequences the projections run as blocks of 128 inside a launch (same kernels, same summation
+        # order per sequence): 200 sequences = one full block and one of 72
+        wide = eng.fork(200)
+        try:
+            pcm2 = np.concatenate([pcm, synth.make_pcm_np(100, 29)])
+            got, lens = wide.transcribe_batch(pcm2)
+            assert got.shape[0] == 200 and (got[:100] == big).all()
+            tail = np.concatenate([eng.transcribe_batch(pcm2[a:a + 16])[0] for a in range(100, 200, 16)])
+            assert (got[100:, :3] == tail[:, :3]).all()
+            assert (got[100:] == tail).all(axis=1).sum() >= 100 - 6
+            again, _ = eng.transcribe_batch(pcm2[128:200])                   # the second block on its own
+            assert (again == got[128:]).all()
+        finally:
+            wide.close()
         # beam search: 9 recordings x 5 beams = 45 sequences (three groups, the last ragged)
         eng.logmel(pcm[:9], want_output=False)
         eng.encode(9, want_output=False)
