@@ -271,10 +271,23 @@ const char* mw_align_last_error(const mw_aligner* a);
 int mw_align_set_weight(mw_aligner* a, const char* name, const void* data, const int64_t* shape, int ndim, int dtype);
 int mw_align_finalize(mw_aligner* a);
 
+/* A second aligner on the same GPU that shares the (finalized) parent's weights and has its own stream and
+ * workspaces: segments are independent, and one segment alone (about 1500 frames) fills a fraction of the chip, so
+ * several in flight from different host threads raise throughput.  Destroy every fork before its parent. */
+int mw_align_fork(mw_aligner* parent, mw_aligner** out);
+
 /* pcm: n_samples float32 mono 16 kHz samples (host or device; the caller normalises them if the checkpoint's
  * feature extractor asks for it) -> out: float32 [n_frames][vocab] log-softmax of the CTC logits (host or device,
  * room for mw_align_frames(desc, n_samples) rows), *n_frames rows written.  Blocks until out is complete. */
 int mw_align_emissions(mw_aligner* a, const float* pcm, int64_t n_samples, float* out, int32_t* n_frames);
+
+/* The search inside whisperx.align (get_trellis + backtrack of its alignment.py, reference transcribe.py:131), on the
+ * host: emission float32 [n_frames][vocab] log-probabilities (host memory), tokens[n_tokens] the ids of the
+ * segment's characters (-1: a character outside the vocabulary, aligned as a wildcard that scores the best
+ * non-blank entry of a frame).  Fills, for every frame t, token_index[t] (which token the best path stands on) and
+ * score[t] (probability of what the path emits there).  MW_ERR_STATE: no path (fewer frames than tokens). */
+int mw_align_path(const float* emission, int32_t n_frames, int32_t vocab, const int32_t* tokens, int32_t n_tokens,
+                  int32_t blank_id, int32_t* token_index, float* score);
 
 #ifdef __cplusplus
 }

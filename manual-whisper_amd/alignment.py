@@ -24,6 +24,8 @@ import ctypes as C
 import json
 import math
 import os
+import queue
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -42,9 +44,13 @@ MIN_SAMPLES = 400                         # shorter segments are zero-padded to 
 # the acoustic model
 # ------------------------------------------------------------------------------------------------
 class Aligner:
-    """A wav2vec2 CTC model on one GPU: ``emissions(wave) -> float32 [frames][vocab]`` log-probabilities."""
+    """A wav2vec2 CTC model on one GPU: ``emissions(wave) -> float32 [frames][vocab]`` log-probabilities.
 
-    def __init__(self, cfg: dict, device: int = 0, max_seconds: int = MAX_ALIGN_SECONDS):
+    ``emissions`` may be called from several threads at once: up to ``n_streams`` calls run concurrently, each on a
+    copy of the workspaces with its own stream (``mw_align_fork``; the weights are shared).  One segment is about
+    1500 frames, a fraction of what fills the GPU."""
+
+    def __init__(self, cfg: dict, device: int = 0, max_seconds: int = MAX_ALIGN_SECONDS, n_streams: int = 8):
         if cfg.get("feat_extract_norm", "group") != "layer" or not cfg.get("do_stable_layer_norm", False) or not cfg.get("conv_bias", False):
             raise EngineError("only the wav2vec2 variant with a layer-norm feature extractor, convolution biases and stable "
                               "layer norm (wav2vec2-large-xlsr-53 and its fine-tunes) is built")
@@ -68,6 +74,10 @@ class Aligner:
         if rc != 0:
             raise EngineError(f"mw_align_create failed ({rc}): {self._lib.mw_align_last_error(None).decode()}")
         self._h = h
+        self.n_streams = max(1, int(n_streams))
+        self._forks: List[C.c_void_p] = []
+        self._free: "queue.Queue" = queue.Queue()
+        self._ready = False
 
     def _check(self, rc: int, what: str):
         if rc != 0:
@@ -89,6 +99,13 @@ class Aligner:
             shp = (C.c_int64 * len(shape))(*shape)
             self._check(self._lib.mw_align_set_weight(self._h, name.encode(), _ptr(w), shp, len(shape), dt), f"mw_align_set_weight({name})")
         self._check(self._lib.mw_align_finalize(self._h), "mw_align_finalize")
+        self._free.put(self._h)
+        for _ in range(self.n_streams - 1):
+            h = C.c_void_p()
+            self._check(self._lib.mw_align_fork(self._h, C.byref(h)), "mw_align_fork")
+            self._forks.append(h)
+            self._free.put(h)
+        self._ready = True
 
     def n_frames(self, n_samples: int) -> int:
         return int(self._lib.mw_align_frames(C.byref(self.desc), int(n_samples)))
@@ -97,10 +114,20 @@ class Aligner:
         wave = np.ascontiguousarray(wave, dtype=np.float32).reshape(-1)
         out = np.empty((max(self.n_frames(len(wave)), 1), self.cfg["vocab_size"]), np.float32)
         n = C.c_int32(0)
-        self._check(self._lib.mw_align_emissions(self._h, _ptr(wave), len(wave), _ptr(out), C.byref(n)), "mw_align_emissions")
+        h = self._free.get() if self._ready else self._h        # before load_weights the call itself reports the state
+        try:
+            rc = self._lib.mw_align_emissions(h, _ptr(wave), len(wave), _ptr(out), C.byref(n))
+            if rc != 0:
+                raise EngineError(f"mw_align_emissions failed ({rc}): {self._lib.mw_align_last_error(h).decode()}")
+        finally:
+            if self._ready:
+                self._free.put(h)
         return out[: n.value]
 
     def close(self):
+        for h in getattr(self, "_forks", []):                  # forks borrow the weights: they go first
+            self._lib.mw_align_destroy(h)
+        self._forks = []
         if getattr(self, "_h", None):
             self._lib.mw_align_destroy(self._h)
             self._h = None
@@ -173,54 +200,23 @@ class Segment:
         return self.end - self.start
 
 
-def wildcard_emission(frame: np.ndarray, tokens: Sequence[int], blank_id: int) -> np.ndarray:
-    """Log-probability of each token in one frame; a wildcard (-1, a character outside the vocabulary) scores
-    the best non-blank entry of the frame."""
-    tok = np.asarray(tokens, np.int64)
-    wild = tok == -1
-    regular = frame[np.where(wild, 0, tok)]
-    if not wild.any():
-        return regular
-    masked = frame.copy()
-    masked[blank_id] = -np.inf
-    return np.where(wild, masked.max(), regular)
-
-
-def get_trellis(emission: np.ndarray, tokens: Sequence[int], blank_id: int = 0) -> np.ndarray:
-    """trellis[t][j]: best log-probability of frames [0, t) with the path standing on token j at frame t.
-    Token 0 holds from frame 0 (its column sums blanks), a move j-1 -> j at frame t pays token j's emission."""
-    emission = np.asarray(emission, np.float32)
-    T, J = emission.shape[0], len(tokens)
-    trellis = np.zeros((T, J), np.float32)
-    trellis[1:, 0] = np.cumsum(emission[1:, blank_id], dtype=np.float32)
-    trellis[0, 1:] = -np.inf
-    if J > 1:
-        trellis[-J + 1:, 0] = np.inf
-    for t in range(T - 1):
-        trellis[t + 1, 1:] = np.maximum(trellis[t, 1:] + emission[t, blank_id],
-                                        trellis[t, :-1] + wildcard_emission(emission[t], tokens[1:], blank_id))
-    return trellis
-
-
-def backtrack(trellis: np.ndarray, emission: np.ndarray, tokens: Sequence[int], blank_id: int = 0) -> Optional[List[Point]]:
-    """The most likely path, walked back greedily from the last frame and the last token."""
-    t, j = trellis.shape[0] - 1, trellis.shape[1] - 1
-    path = [Point(j, t, float(np.exp(emission[t, blank_id])))]
-    while j > 0:
-        if t <= 0:
-            return None
-        p_stay = emission[t - 1, blank_id]
-        p_change = wildcard_emission(emission[t - 1], [tokens[j]], blank_id)[0]
-        stayed = trellis[t - 1, j] + p_stay
-        changed = trellis[t - 1, j - 1] + p_change
-        t -= 1
-        if changed > stayed:
-            j -= 1
-        path.append(Point(j, t, float(np.exp(p_change if changed > stayed else p_stay))))
-    while t > 0:
-        path.append(Point(j, t - 1, float(np.exp(emission[t - 1, blank_id]))))
-        t -= 1
-    return path[::-1]
+def ctc_path(emission: np.ndarray, tokens: Sequence[int], blank_id: int = 0) -> Optional[List[Point]]:
+    """The most likely monotone path of `tokens` (-1: wildcard, a character outside the vocabulary, which scores the
+    best non-blank entry of a frame) through the emissions: one Point per frame, or None when there are fewer frames
+    than tokens.  Trellis and walk back run in libmwhip.so (``mw_align_path``), in float32 like the torch code of
+    whisperx's alignment.py: trellis[t + 1][j] = max(trellis[t][j] + blank(t), trellis[t][j - 1] + token_j(t)), token 0
+    held from frame 0, the walk started on the last token at the last frame."""
+    em = np.ascontiguousarray(emission, dtype=np.float32)
+    tok = np.ascontiguousarray(tokens, dtype=np.int32)
+    T, V = em.shape
+    idx = np.empty(T, np.int32)
+    sc = np.empty(T, np.float32)
+    rc = _lib.load().mw_align_path(em.ctypes.data, T, V, tok.ctypes.data, len(tok), int(blank_id), idx.ctypes.data, sc.ctypes.data)
+    if rc == -2:                                  # MW_ERR_STATE: no path
+        return None
+    if rc != 0:
+        raise EngineError(f"mw_align_path failed ({rc}): bad argument")
+    return [Point(int(j), t, float(p)) for t, (j, p) in enumerate(zip(idx, sc))]
 
 
 def merge_repeats(path: Sequence[Point], transcript: str) -> List[Segment]:
@@ -333,8 +329,8 @@ def align(transcript: Sequence[dict], model: Aligner, align_model_metadata: dict
         if ch in ("[pad]", "<pad>"):
             blank_id = code
 
-    aligned_segments: List[dict] = []
-    for sdx, segment in enumerate(transcript):
+    def align_one(sdx_segment):
+        sdx, segment = sdx_segment
         prep = _prepare(segment, dictionary, lang)
         t1, t2, text = segment["start"], segment["end"], segment["text"]
         fallback = {"start": t1, "end": t2, "text": text, "words": [], "chars": [] if return_char_alignments else None}
@@ -342,26 +338,22 @@ def align(transcript: Sequence[dict], model: Aligner, align_model_metadata: dict
             print(f"Progress: {(sdx + 1) / max(len(transcript), 1) * (50 if combined_progress else 100) + (50 if combined_progress else 0):.2f}%...")
         if not prep["clean_char"]:
             print(f'Failed to align segment ("{text}"): no characters in this segment found in model dictionary, resorting to original...')
-            aligned_segments.append(fallback)
-            continue
+            return [fallback]
         if t1 >= max_duration:
             print(f'Failed to align segment ("{text}"): original start time longer than audio duration, skipping...')
-            aligned_segments.append(fallback)
-            continue
+            return [fallback]
         text_clean = "".join(prep["clean_char"])
         tokens = [dictionary.get(c, -1) for c in text_clean]
         wave = audio[int(t1 * SAMPLE_RATE): int(t2 * SAMPLE_RATE)]
         if len(wave) < MIN_SAMPLES:
             wave = np.pad(wave, (0, MIN_SAMPLES - len(wave)))
         emission = model.emissions(wave)
-        trellis = get_trellis(emission, tokens, blank_id)
-        path = backtrack(trellis, emission, tokens, blank_id)
+        path = ctc_path(emission, tokens, blank_id)
         if path is None:
             print(f'Failed to align segment ("{text}"): backtrack failed, resorting to original...')
-            aligned_segments.append(fallback)
-            continue
+            return [fallback]
         char_segments = merge_repeats(path, text_clean)
-        ratio = (t2 - t1) / (trellis.shape[0] - 1) if trellis.shape[0] > 1 else 0.0
+        ratio = (t2 - t1) / (emission.shape[0] - 1) if emission.shape[0] > 1 else 0.0      # whisperx: duration / (trellis rows - 1)
 
         chars = []
         word_idx = 0
@@ -420,7 +412,17 @@ def align(transcript: Sequence[dict], model: Aligner, align_model_metadata: dict
                     merged[key]["chars"] = merged[key]["chars"] + s["chars"]
             else:
                 merged[key] = dict(s, start=a, end=b)
-        aligned_segments += [merged[k] for k in sorted(merged)]
+        return [merged[k] for k in sorted(merged)]
+
+    # segments are independent: several in flight keep the GPU busy (the model runs up to n_streams at once) and
+    # overlap one segment's search on the host with another's acoustic model; results keep the segments' order
+    workers = max(1, int(getattr(model, "n_streams", 1)))
+    if workers > 1 and len(transcript) > 1:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            parts = list(pool.map(align_one, enumerate(transcript)))
+    else:
+        parts = [align_one(x) for x in enumerate(transcript)]
+    aligned_segments: List[dict] = [seg for part in parts for seg in part]
 
     word_segments: List[dict] = []
     for seg in aligned_segments:

@@ -42,6 +42,7 @@ struct mw_aligner {
     std::string err;
     std::vector<void*> allocs;
     bool finalized = false;
+    mw_aligner* parent = nullptr;                          // a fork borrows its parent's weights
     std::map<std::string, std::vector<float>> host;       // tensors as handed over (float32), until mw_align_finalize
     std::map<std::string, std::vector<int64_t>> shapes;
 
@@ -93,6 +94,23 @@ static long frames_after(const mw_align_desc& d, long n, int upto) {
     return n;
 }
 
+// Everything one stream of work needs besides the weights (a fork owns only this)
+static int alloc_align_work(mw_aligner* a) {
+    const mw_align_desc& d = a->d;
+    a->max_t0 = (int)frames_after(d, d.max_samples, 1);
+    a->max_frames = (int)frames_after(d, d.max_samples, d.n_conv);
+    a->vpad = (d.vocab + 63) / 64 * 64;
+    const size_t C = d.conv_dim, D = d.hidden, F = d.ffn_dim, T = a->max_frames, H = d.n_heads;
+    const size_t Tpad = (T + 7) / 8 * 8;
+    AALLOC(a->pcm, (size_t)d.max_samples);
+    AALLOC(a->h[0], (size_t)a->max_t0 * C); AALLOC(a->h[1], (size_t)frames_after(d, d.max_samples, 2) * C + C);
+    AALLOC(a->x, T * D); AALLOC(a->xn, T * D);
+    AALLOC(a->pack, (size_t)(T + d.pos_kernel) * D);
+    AALLOC(a->q, T * D); AALLOC(a->k, T * D); AALLOC(a->vT, H * 64 * Tpad, true); AALLOC(a->att, T * D); AALLOC(a->hid, T * F);
+    AALLOC(a->logits, T * (size_t)a->vpad);
+    return MW_OK;
+}
+
 extern "C" int64_t mw_align_frames(const mw_align_desc* desc, int64_t n_samples) {
     if (!desc || n_samples < 0) return 0;
     return frames_after(*desc, n_samples, desc->n_conv);
@@ -119,21 +137,24 @@ extern "C" int mw_align_create(const mw_align_desc* desc, int device, mw_aligner
     a->d = d; a->device = device;
     auto bail = [&](int code) { g_align_create_error = a->err; mw_align_destroy(a); return code; };
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) { a->err = "stream creation failed"; return bail(MW_ERR_HIP); }
-    a->max_t0 = (int)frames_after(d, d.max_samples, 1);
-    a->max_frames = (int)frames_after(d, d.max_samples, d.n_conv);
-    a->vpad = (d.vocab + 63) / 64 * 64;
-    auto work = [&]() -> int {
-        const size_t C = d.conv_dim, D = d.hidden, F = d.ffn_dim, T = a->max_frames, H = d.n_heads;
-        const size_t Tpad = (T + 7) / 8 * 8;
-        AALLOC(a->pcm, (size_t)d.max_samples);
-        AALLOC(a->h[0], (size_t)a->max_t0 * C); AALLOC(a->h[1], (size_t)frames_after(d, d.max_samples, 2) * C + C);
-        AALLOC(a->x, T * D); AALLOC(a->xn, T * D);
-        AALLOC(a->pack, (size_t)(T + d.pos_kernel) * D);
-        AALLOC(a->q, T * D); AALLOC(a->k, T * D); AALLOC(a->vT, H * 64 * Tpad, true); AALLOC(a->att, T * D); AALLOC(a->hid, T * F);
-        AALLOC(a->logits, T * (size_t)a->vpad);
-        return MW_OK;
-    };
-    int r = work();
+    int r = alloc_align_work(a);
+    if (r) return bail(r);
+    *out = a;
+    return MW_OK;
+}
+
+extern "C" int mw_align_fork(mw_aligner* parent, mw_aligner** out) {
+    if (!parent || !out) return MW_ERR_ARG;
+    *out = nullptr;
+    if (!parent->finalized) return afail(parent, MW_ERR_STATE, "mw_align_fork: the parent is not finalized");
+    mw_aligner* a = new mw_aligner();
+    a->d = parent->d; a->device = parent->device; a->parent = parent;
+    a->conv = parent->conv; a->proj_ln = parent->proj_ln; a->proj = parent->proj; a->pos_w = parent->pos_w; a->pos_b = parent->pos_b;
+    a->layers = parent->layers; a->enc_ln = parent->enc_ln; a->head = parent->head;
+    a->finalized = true;
+    auto bail = [&](int code) { parent->err = "mw_align_fork: " + a->err; mw_align_destroy(a); return code; };
+    if (hipSetDevice(a->device) != hipSuccess || hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) { a->err = "stream creation failed"; return bail(MW_ERR_HIP); }
+    int r = alloc_align_work(a);
     if (r) return bail(r);
     *out = a;
     return MW_OK;
@@ -153,6 +174,7 @@ extern "C" const char* mw_align_last_error(const mw_aligner* a) { return a ? a->
 extern "C" int mw_align_set_weight(mw_aligner* a, const char* name_c, const void* data, const int64_t* shape, int ndim, int dtype) {
     if (!a) return MW_ERR_ARG;
     if (a->finalized) return afail(a, MW_ERR_STATE, "mw_align_set_weight: already finalized");
+    if (a->parent) return afail(a, MW_ERR_STATE, "mw_align_set_weight: a fork shares its parent's weights");
     if (!name_c || !data || !shape || ndim < 1 || ndim > 3) return afail(a, MW_ERR_ARG, "mw_align_set_weight: null or bad argument");
     if (dtype < MW_F32 || dtype > MW_BF16) return afail(a, MW_ERR_ARG, "mw_align_set_weight: dtype must be MW_F32, MW_F16 or MW_BF16");
     size_t n = 1;
@@ -374,4 +396,62 @@ extern "C" int mw_align_emissions(mw_aligner* a, const float* pcm, int64_t n_sam
     ACHK(hipStreamSynchronize(s));
     *n_frames = T;
     return MW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CTC forced alignment on the host: trellis over (frames, tokens) and the walk back, in float32 like the torch code
+// of whisperx's alignment.py (get_trellis / backtrack, after torchaudio's forced-alignment tutorial).  A token of
+// -1 is a wildcard (a character outside the vocabulary): it scores the best non-blank entry of the frame.
+//   trellis[0][0] = 0, trellis[t][0] = sum of blank log-probabilities of frames 1..t, trellis[0][j > 0] = -inf,
+//   trellis[t][0] = +inf for the last n_tokens - 1 frames (token 0 must have been left by then),
+//   trellis[t + 1][j] = max(trellis[t][j] + blank(t), trellis[t][j - 1] + token_j(t)).
+// The walk starts at the last frame on the last token and moves to token j - 1 wherever that was the larger term.
+extern "C" int mw_align_path(const float* em, int32_t T, int32_t V, const int32_t* tokens, int32_t J, int32_t blank, int32_t* token_index,
+                             float* score) {
+    if (!em || !tokens || !token_index || !score || T < 1 || J < 1 || V < 2 || blank < 0 || blank >= V) return MW_ERR_ARG;
+    bool wild = false;
+    for (int j = 0; j < J; ++j) {
+        if (tokens[j] < -1 || tokens[j] >= V) return MW_ERR_ARG;
+        wild |= tokens[j] == -1;
+    }
+    const float inf = INFINITY;
+    std::vector<float> wmax;
+    if (wild) {
+        wmax.resize(T);
+        for (int t = 0; t < T; ++t) {
+            float m = -inf;
+            const float* row = em + (size_t)t * V;
+            for (int v = 0; v < V; ++v) if (v != blank && row[v] > m) m = row[v];
+            wmax[t] = m;
+        }
+    }
+    auto lp = [&](int t, int j) { return tokens[j] == -1 ? wmax[t] : em[(size_t)t * V + tokens[j]]; };
+    std::vector<float> tr((size_t)T * J);
+    tr[0] = 0.f;
+    for (int t = 1; t < T; ++t) tr[(size_t)t * J] = tr[(size_t)(t - 1) * J] + em[(size_t)t * V + blank];
+    for (int j = 1; j < J; ++j) tr[j] = -inf;
+    if (J > 1) for (int t = std::max(0, T - (J - 1)); t < T; ++t) tr[(size_t)t * J] = inf;
+    for (int t = 0; t + 1 < T; ++t) {
+        const float* cur = &tr[(size_t)t * J];
+        float* nxt = &tr[(size_t)(t + 1) * J];
+        const float b = em[(size_t)t * V + blank];
+        for (int j = 1; j < J; ++j) {
+            const float stay = cur[j] + b, move = cur[j - 1] + lp(t, j);
+            nxt[j] = stay > move ? stay : move;               // max; a NaN (inf - inf) cannot arise: -inf only meets finite terms
+        }
+    }
+    int t = T - 1, j = J - 1, n = 0;
+    auto put = [&](int jj, int tt, float p) { token_index[tt] = jj; score[tt] = expf(p); ++n; };
+    put(j, t, em[(size_t)t * V + blank]);
+    while (j > 0) {
+        if (t <= 0) return MW_ERR_STATE;                       // fewer frames than tokens: no path
+        const float p_stay = em[(size_t)(t - 1) * V + blank], p_change = lp(t - 1, j);
+        const float stayed = tr[(size_t)(t - 1) * J + j] + p_stay, changed = tr[(size_t)(t - 1) * J + j - 1] + p_change;
+        --t;
+        const bool ch = changed > stayed;
+        if (ch) --j;
+        put(j, t, ch ? p_change : p_stay);
+    }
+    while (t > 0) { put(j, t - 1, em[(size_t)(t - 1) * V + blank]); --t; }
+    return n == T ? MW_OK : MW_ERR_STATE;
 }

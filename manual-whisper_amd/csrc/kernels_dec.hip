@@ -1723,15 +1723,21 @@ void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out,
     const dim3 g1(B * H * kXattnSplit), g2(H * kXattnSplit, B);
     const DecState* nost = nullptr;
     const int* norows = nullptr;
+    // Launches of many rounds (decode groups): an LDS request that nothing uses holds the kernel to three workgroups
+    // per CU instead of five.  Three workgroups' loads in flight already cover the HBM round trip; a deeper queue
+    // only delays everyone's requests, this kernel's own included: 6.18 -> 6.44 TB/s alone at 112 sequences
+    // (two per CU: 5.80), the benchmark step 160.5 -> 159.0 ms.  Launches that fit the chip in one round keep five.
+    static const int xlds_env = getenv("MW_XATTN_LDS") ? atoi(getenv("MW_XATTN_LDS")) : -1;
+    const size_t xlds = xlds_env >= 0 ? (size_t)xlds_env : ((long)B * H * kXattnSplit >= 2 * 1280 ? 40000 : 0);
     if (kv_div > 1) {
-        if (done) hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true, true>), g2, dim3(256), 0, s, q, kc, vc, out, H, T, T,
+        if (done) hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true, true>), g2, dim3(256), xlds, s, q, kc, vc, out, H, T, T,
                                      nost, partial, tickets, kv_div, norows, row0, done, done_div);
-        else hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true>), g1, dim3(256), 0, s, q, kc, vc, out, H, T, T, nost,
+        else hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true>), g1, dim3(256), xlds, s, q, kc, vc, out, H, T, T, nost,
                                 partial, tickets, kv_div, norows, row0, done, done_div);
     } else {
-        if (done) hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, false, true>), g2, dim3(256), 0, s, q, kc, vc, out, H, T, T,
+        if (done) hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, false, true>), g2, dim3(256), xlds, s, q, kc, vc, out, H, T, T,
                                      nost, partial, tickets, 1, norows, B, done, done_div);
-        else hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), g1, dim3(256), 0, s, q, kc, vc, out, H, T, T, nost, partial,
+        else hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit>), g1, dim3(256), xlds, s, q, kc, vc, out, H, T, T, nost, partial,
                                 tickets, 1, norows, B, done, done_div);
     }
 }
