@@ -540,17 +540,11 @@ void launch_t(const GemmParams& p, hipStream_t s) {
 // half h of B is columns wc*64 + h*32 + [0,32) of all four wave columns, so that a quadrant
 // (ha, hb) of every wave's output needs exactly half-tiles A[ha] and B[hb].
 //
-// A K-tile is four phases, one quadrant each, in the order (0,0) (0,1) (1,1) (1,0); a phase is
-//     ds_read the half-tile(s) the quadrant adds | issue ONE half-tile of LDS-DMA prefetch |
-//     counted vmcnt | barrier | 16 MFMA | barrier
-// and the two wave rows run one barrier apart, so the wave that shares a SIMD with an MFMA-ing
-// wave is the one doing LDS reads and prefetch.  Prefetch order and distance: phase 1 of tile t
-// issues B1(t+1), phase 2 A1(t+1), phase 3 A0(t+2), phase 4 B0(t+2): four half-tiles (8 DMA
-// instructions per wave) stay in flight across the barriers, hence vmcnt(8); never 0 in the loop.
-// Hazards (with the stagger): a half-tile is read one phase AFTER the phase whose vmcnt retired it
-// (every wave waits for its own DMA, then a barrier), and a slot is refilled at least two phases
-// after the phase that last read it (A0: read ph.1 -> refilled ph.3; B0: ph.1 -> ph.4, B0 stays
-// in registers for the last quadrant; B1: ph.2 -> ph.1 of the next tile; A1: ph.3 -> ph.2).
+// The K loop (two phases of 32 MFMAs per K-tile, the two wave rows one barrier apart, LDS-DMA prefetch with counted
+// vmcnt) is described at the `ktile` lambda.  Measured with in-kernel stamps (-DMW_GEMM_STAMPS): 1.48 us per K-tile
+// of 64, where the MFMAs alone take 1.05 us at the ~1.95 GHz the chip holds under this load: a wave's read
+// section (24 ds_read_b128 and 8 LDS-DMA instructions per K-tile, the latter 60-185 cycles each to issue) is as
+// long as its partner's MFMA section.  Four phases of 16 MFMAs (twice the barriers) were 2 % slower.
 constexpr int kHalfSlot = 128 * BK;          // halfs per half-tile slot
 enum { SLOT_A0 = 0, SLOT_A1 = 1, SLOT_B0 = 2, SLOT_B1 = 3 };
 
@@ -709,8 +703,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    // MODE 0: steady state; 1: second-to-last K-tile (nothing left to issue in phases 3, 4);
-    // 2: last K-tile (nothing to issue, the remaining DMA drains 2 -> 0)
+    // A K-tile is TWO phases of 32 MFMAs: Q1 = A0 x (B0, B1), Q2 = A1 x (B1, B0) (B stays in registers).  A phase is
+    //     ds_read what it adds | issue LDS-DMA prefetch | counted vmcnt | lgkmcnt(0) | barrier | 32 MFMA | barrier
+    // and the two wave rows run one barrier apart, so the wave that shares a SIMD with an MFMA-ing wave is the one
+    // doing LDS reads and prefetch.  Prefetch: Q1 of tile t issues A1(t+1) (its slot was read in Q2(t-1)), Q2 of
+    // tile t issues A0, B0, B1 of tile t+2 into the slots Q1(t) has just read: a slot is refilled in the phase
+    // after its last read, which is safe because every wave drains its LDS reads (lgkmcnt(0)) before the barrier
+    // that ends its read section, and both wave rows have passed that barrier before anyone's next read section.
+    // A half-tile is read one phase after the phase whose vmcnt retired it (every wave waits for its own DMA, then a
+    // barrier); 8 DMA instructions per wave stay in flight across the barriers, hence vmcnt(8), never 0 in the loop.
+    // MODE 0: steady state; 1: second-to-last K-tile (no tile t+2); 2: last K-tile (nothing to issue).
     auto ktile = [&](auto bufc, auto modec, int t) {
         constexpr int BUF = decltype(bufc)::value, MODE = decltype(modec)::value;
         // fp8 form: the second buffer lies past the 64 KB reach of a ds_read offset, and left alone the compiler keeps
@@ -719,41 +721,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         int buf_off = BUF * 4 * kHalfSlot;
         if constexpr (F8 && BUF == 1) asm volatile("" : "+s"(buf_off));
         const f16* cur = lds + buf_off;
-        // phase 1: quadrant (0,0)
+        // Q1
         read_b(cur + SLOT_B0 * kHalfSlot, b0f);
         read_a(cur + SLOT_A0 * kHalfSlot);
-        if constexpr (MODE < 2) issue(BUF ^ 1, SLOT_B1, false, 1, t + 1);
-        wait_vm<MODE < 2 ? 8 : 2>();
-        __builtin_amdgcn_s_barrier();
-        quadrant(I0{}, I0{}, b0f);
-        __builtin_amdgcn_s_barrier();
-        // phase 2: quadrant (0,1)
         read_b(cur + SLOT_B1 * kHalfSlot, b1f);
         if constexpr (MODE < 2) issue(BUF ^ 1, SLOT_A1, true, 1, t + 1);
         wait_vm<MODE < 2 ? 8 : 0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        quadrant(I0{}, I0{}, b0f);
         quadrant(I0{}, I1{}, b1f);
         __builtin_amdgcn_s_barrier();
-        // phase 3: quadrant (1,1)
+        // Q2
         read_a(cur + SLOT_A1 * kHalfSlot);
-        if constexpr (MODE == 0) issue(BUF, SLOT_A0, true, 0, t + 2);
+        if constexpr (MODE == 0) {
+            issue(BUF, SLOT_A0, true, 0, t + 2);
+            issue(BUF, SLOT_B0, false, 0, t + 2);
+            issue(BUF, SLOT_B1, false, 1, t + 2);
+        }
+        if constexpr (MODE < 2) wait_vm<MODE == 0 ? 8 : 2>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         quadrant(I1{}, I1{}, b1f);
-        __builtin_amdgcn_s_barrier();
-        // phase 4: quadrant (1,0), B0 still in registers
-        if constexpr (MODE == 0) issue(BUF, SLOT_B0, false, 0, t + 2);
-        if constexpr (MODE < 2) wait_vm<MODE == 0 ? 8 : 4>();
-        __builtin_amdgcn_s_barrier();
         quadrant(I1{}, I0{}, b0f);
         __builtin_amdgcn_s_barrier();
     };
 
     const int nk = p.K / BK;                         // even and >= 2 (checked by the launcher)
     MW_STAMP(0);
-    issue(0, SLOT_A0, true, 0, 0); issue(0, SLOT_B0, false, 0, 0);
-    issue(0, SLOT_B1, false, 1, 0); issue(0, SLOT_A1, true, 1, 0);
-    issue(1, SLOT_A0, true, 0, 1); issue(1, SLOT_B0, false, 0, 1);
-    wait_vm<8>();                                    // A0, B0 of tile 0 have landed
+    issue(0, SLOT_A0, true, 0, 0); issue(0, SLOT_B0, false, 0, 0); issue(0, SLOT_B1, false, 1, 0);
+    issue(0, SLOT_A1, true, 1, 0);
+    issue(1, SLOT_A0, true, 0, 1); issue(1, SLOT_B0, false, 0, 1); issue(1, SLOT_B1, false, 1, 1);
+    wait_vm<8>();                                    // A0, B0, B1 of tile 0 have landed
     __builtin_amdgcn_s_barrier();
     MW_STAMP(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();       // second wave row runs one barrier behind
