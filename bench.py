@@ -181,6 +181,35 @@ def fp8_b32_run(dims, opts, dev, local_rank):
     return out
 
 
+def align_side_run(local_rank, n_seg=32):
+    """The step after the hot path in the reference (transcribe.py:127-135): forced alignment of every segment with a
+    wav2vec2-large-xlsr-53-shaped CTC model (synthetic weights, vocabulary 3503), `n_seg` windows of 30 s with 150
+    characters each through alignment.align()."""
+    from manual_whisper_amd import alignment, localckpt, synth
+    cfg = localckpt.wav2vec2_config("w2v-large")
+    model = alignment.Aligner(cfg, device=local_rank, max_seconds=30)
+    model.load_weights(localckpt.make_wav2vec2_weights_np(cfg, 77))
+    vocab = localckpt.synthetic_ctc_vocab(cfg["vocab_size"])
+    chars = [c for c in vocab if len(c) == 1 and ord(c) >= 0x4E00]
+    meta = {"language": "zh", "dictionary": vocab, "type": "huggingface"}
+    audio = np.tile(synth.hash_uniform_np(30 * 16000, "wave.bench", 5) * np.float32(0.6), n_seg)
+    rng = np.random.default_rng(1)
+    segs = [{"text": "".join(rng.choice(chars, 150)), "start": 30.0 * i, "end": 30.0 * (i + 1)} for i in range(n_seg)]
+    alignment.align(segs[:model.n_streams], model, meta, audio, "cuda")
+    t = time.perf_counter()
+    res = alignment.align(segs, model, meta, audio, "cuda")
+    dt = time.perf_counter() - t
+    t = time.perf_counter()
+    model.emissions(audio[:480000])
+    one = time.perf_counter() - t
+    model.close()
+    return {"workload": f"alignment.align() over {n_seg} windows of 30 s x 150 characters, wav2vec2-large-xlsr-53 geometry (24 layers of 1024, "
+                        f"vocabulary {cfg['vocab_size']}), synthetic weights, {model.n_streams} segments in flight, host buffers in and out",
+            "value": round(n_seg * 30 / dt, 1), "unit": "audio-seconds/second", "ms_per_window": round(dt / n_seg * 1e3, 2),
+            "one_window_alone_ms": round(one * 1e3, 2), "words": len(res["word_segments"]),
+            "note": "outside the headline metric: the reference runs this after model.transcribe"}
+
+
 def free_port() -> int:
     import socket
     with socket.socket() as so:
@@ -222,6 +251,7 @@ def main(argv=None):
     ap.add_argument("--also-engines", type=int, default=3)
     ap.add_argument("--no-ungrouped", action="store_true", help="N=1 only: skip the side measurement with --group 1 --engines 4")
     ap.add_argument("--no-fp8-b32", action="store_true", help="N=1 only: skip the configs[4] side measurement (fp8 weights, batch 32)")
+    ap.add_argument("--no-align", action="store_true", help="N=1 only: skip the forced-alignment side measurement")
     ap.add_argument("--batch", type=int, default=16, help="30 s chunks per step per GPU (configs[4] uses 32)")
     ap.add_argument("--tokens", type=int, default=NEW_TOKENS, help="sampled tokens per chunk (the metric is quoted at 128; 32 and 224 are the side cases)")
     args = ap.parse_args(argv)
@@ -393,6 +423,8 @@ def main(argv=None):
             out["ungrouped"]["workload"] = "as config.workload, but 4 engines in flight that each run whole passes of 16 chunks (decode per step)"
         if world == 1 and not args.no_fp8_b32 and args.model == MODEL and args.weights == "f16":
             out["fp8_b32"] = fp8_b32_run(dims, opts, dev, local_rank)
+        if world == 1 and not args.no_align and args.model == MODEL:
+            out["align"] = align_side_run(local_rank)
         if weights_np is not None:
             def gpu_ids(pcm, n_new):
                 o = synthetic_options(dims, max_new=n_new, suppress_eot=True)

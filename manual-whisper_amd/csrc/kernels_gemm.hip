@@ -579,7 +579,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    constexpr int GROUP_M = 8;
+    #ifdef MW_GROUP_M                     // tuning builds
+    constexpr int GROUP_M = MW_GROUP_M;
+#else
+    constexpr int GROUP_M = 4;        // M = 24000, K = 1280: 4 row tiles per column tile beat 8 by 2-4 % (N = 1280, 3840; K = 5120), 2 and 16 lose
+#endif
     const int per_group = GROUP_M * nt_n;
     const int group = bid / per_group;
     const int gm0 = group * GROUP_M;

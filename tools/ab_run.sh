@@ -5,7 +5,7 @@ args=()
 while [ "$1" != "--" ]; do args+=("$1"); shift; done
 shift
 for v in "$@"; do
-  MW_LIB_PATH=$PWD/tools/ab/$v/libmwhip.so timeout -k 10 300 python bench.py --no-cpu-baseline --also-batch 0 --no-fp8-b32 --no-ungrouped "${args[@]}" > ${out}_$v.log 2>&1 || { echo "variant $v failed"; tail -5 ${out}_$v.log; exit 1; }
+  MW_LIB_PATH=$PWD/tools/ab/$v/libmwhip.so timeout -k 10 300 python bench.py --no-cpu-baseline --also-batch 0 --no-fp8-b32 --no-ungrouped --no-align "${args[@]}" > ${out}_$v.log 2>&1 || { echo "variant $v failed"; tail -5 ${out}_$v.log; exit 1; }
   python - "$v" ${out}_$v.log <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

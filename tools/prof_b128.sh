@@ -7,7 +7,7 @@ O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/t -o t --output-format csv -- python3 bench.py --no-cpu-baseline --also-batch 0 --no-fp8-b32 --no-ungrouped --group 1 --engines 1 --batch 128 --steps 2 --warmup 1 > $O/run.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/t -o t --output-format csv -- python3 bench.py --no-cpu-baseline --also-batch 0 --no-fp8-b32 --no-ungrouped --no-align --group 1 --engines 1 --batch 128 --steps 2 --warmup 1 > $O/run.log 2>&1
 cp $(find $O/t -name "*_kernel_stats.csv") $O/kernel_stats.csv
 rm -rf $O/t
 python3 - $O/kernel_stats.csv <<'PY'

@@ -8,7 +8,7 @@ mkdir -p $O/keep
 cd $R
 ks() {   # ks <tag> <bench args...>
   tag=$1; shift
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/$tag -o $tag --output-format csv -- python3 bench.py --no-cpu-baseline --no-fp8-b32 --no-ungrouped "$@" > $O/keep/$tag.log 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/$tag -o $tag --output-format csv -- python3 bench.py --no-cpu-baseline --no-fp8-b32 --no-ungrouped --no-align "$@" > $O/keep/$tag.log 2>&1
   cp $(find $O/$tag -name "*_kernel_stats.csv") $O/keep/kernel_stats_$tag.csv
   rm -rf $O/$tag
   echo "stats $tag done"
