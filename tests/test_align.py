@@ -322,3 +322,36 @@ def test_gpu_full_size_model_matches_the_oracle():
     _check_emissions(got, want, 0.1)
     assert got30.shape == (1499, 3503) and np.isfinite(got30).all()
     np.testing.assert_allclose(np.exp(got30.astype(np.float64)).sum(-1), 1.0, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_cli_aligns_segments_when_a_model_directory_is_given(tmp_path):
+    """`python transcribe.py x.wav` with MW_ALIGN_MODEL set (reference transcribe.py:127-135): every segment of the
+    JSON carries words whose times lie inside the segment's speech window, and the result keeps word_segments."""
+    import json
+    import subprocess
+    import sys
+    from manual_whisper_amd import audio as aud
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sr = 16000
+    x = synth.make_pcm_np(3, seed=71).reshape(-1)[: sr * 70].copy()      # speech 0-25 s, silence, speech 40-65 s, silence
+    x[25 * sr: 40 * sr] = 0.0
+    x[65 * sr:] = 0.0
+    wav = tmp_path / "meeting.wav"
+    aud.write_wav(str(wav), x)
+    w2v = str(tmp_path / "w2v")
+    localckpt.write_synthetic_wav2vec2(w2v, "w2v-micro")
+    env = dict(os.environ, WHISPER_MODEL="synthetic:micro", BATCH_SIZE="2", MW_ENGINES="2", MW_ALIGN_MODEL=w2v)
+    r = subprocess.run([sys.executable, os.path.join(root, "transcribe.py"), str(wav)], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "对齐时间戳" in r.stdout and "对齐耗时" in r.stdout
+    js = json.loads((tmp_path / "meeting_transcript.json").read_text(encoding="utf-8"))
+    assert len(js["segments"]) == 2 and js["word_segments"]
+    for seg, (wa, wb) in zip(js["segments"], [(0.0, 25.0), (40.0, 65.0)]):
+        assert seg["words"], seg
+        assert wa - 0.2 <= seg["start"] <= seg["end"] <= wb + 0.3
+        for w in seg["words"]:
+            assert seg["start"] - 1e-6 <= w["start"] <= w["end"] <= seg["end"] + 1e-6 and 0.0 <= w["score"] <= 1.0
+        # the synthetic Whisper checkpoint has no tokenizer: the text is "<|id|>..." and every character is a word for "zh"
+        assert "".join(w["word"] for w in seg["words"]) == seg["text"].replace(" ", "")
