@@ -289,6 +289,12 @@ int mw_align_emissions(mw_aligner* a, const float* pcm, int64_t n_samples, float
 int mw_align_path(const float* emission, int32_t n_frames, int32_t vocab, const int32_t* tokens, int32_t n_tokens,
                   int32_t blank_id, int32_t* token_index, float* score);
 
+/* mw_align_emissions followed by mw_align_path for one segment, without bringing the emissions to the host: only the
+ * columns the search reads (the blank and the segment's 1..1024 tokens) are gathered on the GPU and copied.  pcm as
+ * for mw_align_emissions; token_index and score need room for mw_align_frames(desc, n_samples) entries. */
+int mw_align_segment(mw_aligner* a, const float* pcm, int64_t n_samples, const int32_t* tokens, int32_t n_tokens,
+                     int32_t blank_id, int32_t* token_index, float* score, int32_t* n_frames);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ SYMBOLS = (
     "mw_logmel", "mw_logmel_noalloc", "mw_encode", "mw_encode_into", "mw_set_encoded", "mw_decode_greedy", "mw_decode_beam", "mw_decode_forced", "mw_transcribe_batch",
     "mw_frame_energy_db", "mw_stage_ms", "mw_profile_cross_attention", "mw_profile_decode_gemvs", "mw_set_option", "mw_synchronize",
     "mw_align_frames", "mw_align_create", "mw_align_destroy", "mw_align_last_error", "mw_align_set_weight", "mw_align_finalize",
-    "mw_align_emissions", "mw_align_fork", "mw_align_path",
+    "mw_align_emissions", "mw_align_fork", "mw_align_path", "mw_align_segment",
 )
 
 
@@ -115,6 +115,7 @@ def load() -> C.CDLL:
     lib.mw_align_finalize.argtypes = [vp]
     lib.mw_align_emissions.argtypes = [vp, f32p, C.c_int64, f32p, C.POINTER(C.c_int32)]
     lib.mw_align_fork.argtypes = [vp, C.POINTER(vp)]
+    lib.mw_align_segment.argtypes = [vp, f32p, C.c_int64, vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
     lib.mw_align_path.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp]
     for name in SYMBOLS:
         if name not in ("mw_destroy", "mw_last_error", "mw_align_destroy", "mw_align_last_error", "mw_align_frames"):

@@ -124,6 +124,35 @@ class Aligner:
                 self._free.put(h)
         return out[: n.value]
 
+    MAX_SEGMENT_TOKENS = 1024
+
+    def segment_path(self, wave, tokens: Sequence[int], blank_id: int = 0):
+        """``ctc_path(self.emissions(wave), tokens, blank_id)`` in one call (``mw_align_segment``): the emissions stay on
+        the GPU, only the columns of the blank and of the segment's tokens come to the host.
+        -> (path or None, number of frames)."""
+        if len(tokens) > self.MAX_SEGMENT_TOKENS:
+            em = self.emissions(wave)
+            return ctc_path(em, tokens, blank_id), em.shape[0]
+        wave = np.ascontiguousarray(wave, dtype=np.float32).reshape(-1)
+        tok = np.ascontiguousarray(tokens, dtype=np.int32)
+        T = max(self.n_frames(len(wave)), 1)
+        idx, sc = np.empty(T, np.int32), np.empty(T, np.float32)
+        n = C.c_int32(0)
+        h = self._free.get() if self._ready else self._h
+        try:
+            rc = self._lib.mw_align_segment(h, _ptr(wave), len(wave), tok.ctypes.data, len(tok), int(blank_id), idx.ctypes.data,
+                                            sc.ctypes.data, C.byref(n))
+            if rc not in (0, -2):
+                raise EngineError(f"mw_align_segment failed ({rc}): {self._lib.mw_align_last_error(h).decode()}")
+        finally:
+            if self._ready:
+                self._free.put(h)
+        if rc == -2 and n.value == 0:                           # MW_ERR_STATE before the model ran: not finalized
+            raise EngineError(f"mw_align_segment failed ({rc}): {self._lib.mw_align_last_error(h).decode()}")
+        if rc == -2:
+            return None, n.value
+        return [Point(int(j), t, float(p)) for t, (j, p) in enumerate(zip(idx[: n.value], sc[: n.value]))], n.value
+
     def close(self):
         for h in getattr(self, "_forks", []):                  # forks borrow the weights: they go first
             self._lib.mw_align_destroy(h)
@@ -347,13 +376,16 @@ def align(transcript: Sequence[dict], model: Aligner, align_model_metadata: dict
         wave = audio[int(t1 * SAMPLE_RATE): int(t2 * SAMPLE_RATE)]
         if len(wave) < MIN_SAMPLES:
             wave = np.pad(wave, (0, MIN_SAMPLES - len(wave)))
-        emission = model.emissions(wave)
-        path = ctc_path(emission, tokens, blank_id)
+        if hasattr(model, "segment_path"):
+            path, n_frames = model.segment_path(wave, tokens, blank_id)
+        else:                                                   # any object with emissions(wave) -> [frames][vocab]
+            emission = model.emissions(wave)
+            path, n_frames = ctc_path(emission, tokens, blank_id), emission.shape[0]
         if path is None:
             print(f'Failed to align segment ("{text}"): backtrack failed, resorting to original...')
             return [fallback]
         char_segments = merge_repeats(path, text_clean)
-        ratio = (t2 - t1) / (emission.shape[0] - 1) if emission.shape[0] > 1 else 0.0      # whisperx: duration / (trellis rows - 1)
+        ratio = (t2 - t1) / (n_frames - 1) if n_frames > 1 else 0.0      # whisperx: duration / (trellis rows - 1)
 
         chars = []
         word_idx = 0

@@ -35,6 +35,8 @@ struct Layer { Norm ln1, ln2; Lin qkv, out, fc1, fc2; };
 
 }  // namespace
 
+constexpr int kMaxSegmentTokens = 1024;                    // characters one mw_align_segment call places
+
 struct mw_aligner {
     mw_align_desc d{};
     int device = 0;
@@ -60,6 +62,8 @@ struct mw_aligner {
     f16* pack = nullptr;                                   // [G][T + K][D/G]
     f16 *q = nullptr, *k = nullptr, *vT = nullptr, *att = nullptr, *hid = nullptr;
     float* logits = nullptr;                               // [T][vpad]
+    int32_t* tok_dev = nullptr;                            // [kMaxSegmentTokens]
+    float* gath_dev = nullptr; float* gath_host = nullptr; // [T][1 + n_tokens] gathered log-probabilities (device; pinned host)
     int max_frames = 0, max_t0 = 0;
 };
 
@@ -108,6 +112,11 @@ static int alloc_align_work(mw_aligner* a) {
     AALLOC(a->pack, (size_t)(T + d.pos_kernel) * D);
     AALLOC(a->q, T * D); AALLOC(a->k, T * D); AALLOC(a->vT, H * 64 * Tpad, true); AALLOC(a->att, T * D); AALLOC(a->hid, T * F);
     AALLOC(a->logits, T * (size_t)a->vpad);
+    AALLOC(a->tok_dev, (size_t)kMaxSegmentTokens);
+    AALLOC(a->gath_dev, T * (size_t)(kMaxSegmentTokens + 1));
+    if (hipHostMalloc(reinterpret_cast<void**>(&a->gath_host), T * (size_t)(kMaxSegmentTokens + 1) * 4, hipHostMallocDefault) != hipSuccess) {
+        a->err = "hipHostMalloc failed"; return MW_ERR_NOMEM;
+    }
     return MW_OK;
 }
 
@@ -165,6 +174,7 @@ extern "C" void mw_align_destroy(mw_aligner* a) {
     (void)hipSetDevice(a->device);
     if (a->stream) (void)hipStreamSynchronize(a->stream);
     for (void* p : a->allocs) (void)hipFree(p);
+    if (a->gath_host) (void)hipHostFree(a->gath_host);
     if (a->stream) (void)hipStreamDestroy(a->stream);
     delete a;
 }
@@ -322,14 +332,13 @@ static GemmParams agemm(const f16* A, long lda, const f16* W, long ldw, int M, i
     return p;
 }
 
-extern "C" int mw_align_emissions(mw_aligner* a, const float* pcm, int64_t n_samples, float* out, int32_t* n_frames) {
-    if (!a) return MW_ERR_ARG;
-    if (!a->finalized) return afail(a, MW_ERR_STATE, "mw_align_emissions: mw_align_finalize has not succeeded yet");
-    if (!pcm || !out || !n_frames) return afail(a, MW_ERR_ARG, "mw_align_emissions: null argument");
+// Queue the acoustic model on the aligner's stream: pcm -> log-probabilities in a->logits [T][vpad] (no wait)
+static int run_model(mw_aligner* a, const float* pcm, int64_t n_samples, int* n_frames, const char* who) {
+    if (!a->finalized) return afail(a, MW_ERR_STATE, std::string(who) + ": mw_align_finalize has not succeeded yet");
     const mw_align_desc& d = a->d;
-    if (n_samples > d.max_samples) return afail(a, MW_ERR_ARG, "mw_align_emissions: more than max_samples samples (" + std::to_string(d.max_samples) + ")");
+    if (n_samples > d.max_samples) return afail(a, MW_ERR_ARG, std::string(who) + ": more than max_samples samples (" + std::to_string(d.max_samples) + ")");
     const int T = (int)frames_after(d, n_samples, d.n_conv);
-    if (T < 1) return afail(a, MW_ERR_ARG, "mw_align_emissions: the input is shorter than one frame of the feature extractor");
+    if (T < 1) return afail(a, MW_ERR_ARG, std::string(who) + ": the input is shorter than one frame of the feature extractor");
     ACHK(hipSetDevice(a->device));
     hipStream_t s = a->stream;
     const int C = d.conv_dim, D = d.hidden, F = d.ffn_dim, H = d.n_heads, G = d.pos_groups, K = d.pos_kernel, W = D / G;
@@ -358,9 +367,10 @@ extern "C" int mw_align_emissions(mw_aligner* a, const float* pcm, int64_t n_sam
     }
     // ---- x += GELU(grouped positional convolution of x): one GEMM per group over the group-major padded copy
     launch_w2v_pos_pack(a->x, a->pack, T, D, G, K, s);
-    for (int g = 0; g < G; ++g) {
-        GemmParams p = agemm(a->pack + (size_t)g * (T + K) * W, W, a->pos_w + (size_t)g * W * K * W, (long)K * W, T, W, K * W, a->pos_b + g * W);
-        p.gelu = 1; p.out_mode = OUT_RESID_F32; p.C = a->x + g * W; p.ldc = D;
+    {   // all groups in one launch: a group alone is a dozen workgroups looping over K = pos_kernel * W
+        GemmParams p = agemm(a->pack, W, a->pos_w, (long)K * W, T, W, K * W, a->pos_b);
+        p.gelu = 1; p.out_mode = OUT_RESID_F32; p.C = a->x; p.ldc = D;
+        p.groups = G; p.a_group_stride = (long)(T + K) * W; p.w_group_stride = (long)W * K * W; p.c_group_stride = W;
         launch_gemm(p, s);
     }
     // ---- transformer layers (pre-LayerNorm), then the encoder's final LayerNorm
@@ -392,8 +402,18 @@ extern "C" int mw_align_emissions(mw_aligner* a, const float* pcm, int64_t n_sam
     }
     launch_log_softmax_rows(a->logits, T, a->vpad, d.vocab, s);
     ACHK(hipGetLastError());
-    ACHK(hipMemcpy2DAsync(out, (size_t)d.vocab * 4, a->logits, (size_t)a->vpad * 4, (size_t)d.vocab * 4, T, hipMemcpyDefault, s));
-    ACHK(hipStreamSynchronize(s));
+    *n_frames = T;
+    return MW_OK;
+}
+
+extern "C" int mw_align_emissions(mw_aligner* a, const float* pcm, int64_t n_samples, float* out, int32_t* n_frames) {
+    if (!a) return MW_ERR_ARG;
+    if (!pcm || !out || !n_frames) return afail(a, MW_ERR_ARG, "mw_align_emissions: null argument");
+    int T = 0;
+    if (int r = run_model(a, pcm, n_samples, &T, "mw_align_emissions")) return r;
+    const mw_align_desc& d = a->d;
+    ACHK(hipMemcpy2DAsync(out, (size_t)d.vocab * 4, a->logits, (size_t)a->vpad * 4, (size_t)d.vocab * 4, T, hipMemcpyDefault, a->stream));
+    ACHK(hipStreamSynchronize(a->stream));
     *n_frames = T;
     return MW_OK;
 }
@@ -406,6 +426,41 @@ extern "C" int mw_align_emissions(mw_aligner* a, const float* pcm, int64_t n_sam
 //   trellis[t][0] = +inf for the last n_tokens - 1 frames (token 0 must have been left by then),
 //   trellis[t + 1][j] = max(trellis[t][j] + blank(t), trellis[t][j - 1] + token_j(t)).
 // The walk starts at the last frame on the last token and moves to token j - 1 wherever that was the larger term.
+// `blank` [T] and `lp` [T][J] hold the only entries of the emissions the search reads: the blank's log-probability per
+// frame, and per frame and token the token's (a wildcard's: the best non-blank entry of the frame).
+static int path_search(const float* blank, const float* lp, int T, int J, long ld, int32_t* token_index, float* score) {
+    const float inf = INFINITY;
+    std::vector<float> tr((size_t)T * J);
+    tr[0] = 0.f;
+    for (int t = 1; t < T; ++t) tr[(size_t)t * J] = tr[(size_t)(t - 1) * J] + blank[t];
+    for (int j = 1; j < J; ++j) tr[j] = -inf;
+    if (J > 1) for (int t = std::max(0, T - (J - 1)); t < T; ++t) tr[(size_t)t * J] = inf;
+    for (int t = 0; t + 1 < T; ++t) {
+        const float* cur = &tr[(size_t)t * J];
+        float* nxt = &tr[(size_t)(t + 1) * J];
+        const float b = blank[t];
+        const float* l = lp + (size_t)t * ld;
+        for (int j = 1; j < J; ++j) {
+            const float stay = cur[j] + b, move = cur[j - 1] + l[j];
+            nxt[j] = stay > move ? stay : move;               // max; a NaN (inf - inf) cannot arise: -inf only meets finite terms
+        }
+    }
+    int t = T - 1, j = J - 1, n = 0;
+    auto put = [&](int jj, int tt, float p) { token_index[tt] = jj; score[tt] = expf(p); ++n; };
+    put(j, t, blank[t]);
+    while (j > 0) {
+        if (t <= 0) return MW_ERR_STATE;                       // fewer frames than tokens: no path
+        const float p_stay = blank[t - 1], p_change = lp[(size_t)(t - 1) * ld + j];
+        const float stayed = tr[(size_t)(t - 1) * J + j] + p_stay, changed = tr[(size_t)(t - 1) * J + j - 1] + p_change;
+        --t;
+        const bool ch = changed > stayed;
+        if (ch) --j;
+        put(j, t, ch ? p_change : p_stay);
+    }
+    while (t > 0) { put(j, t - 1, blank[t - 1]); --t; }
+    return n == T ? MW_OK : MW_ERR_STATE;
+}
+
 extern "C" int mw_align_path(const float* em, int32_t T, int32_t V, const int32_t* tokens, int32_t J, int32_t blank, int32_t* token_index,
                              float* score) {
     if (!em || !tokens || !token_index || !score || T < 1 || J < 1 || V < 2 || blank < 0 || blank >= V) return MW_ERR_ARG;
@@ -414,44 +469,43 @@ extern "C" int mw_align_path(const float* em, int32_t T, int32_t V, const int32_
         if (tokens[j] < -1 || tokens[j] >= V) return MW_ERR_ARG;
         wild |= tokens[j] == -1;
     }
-    const float inf = INFINITY;
-    std::vector<float> wmax;
-    if (wild) {
-        wmax.resize(T);
-        for (int t = 0; t < T; ++t) {
-            float m = -inf;
-            const float* row = em + (size_t)t * V;
-            for (int v = 0; v < V; ++v) if (v != blank && row[v] > m) m = row[v];
-            wmax[t] = m;
-        }
+    std::vector<float> b(T), lp((size_t)T * J);
+    for (int t = 0; t < T; ++t) {
+        const float* row = em + (size_t)t * V;
+        float m = -INFINITY;
+        if (wild) for (int v = 0; v < V; ++v) if (v != blank && row[v] > m) m = row[v];
+        b[t] = row[blank];
+        for (int j = 0; j < J; ++j) lp[(size_t)t * J + j] = tokens[j] == -1 ? m : row[tokens[j]];
     }
-    auto lp = [&](int t, int j) { return tokens[j] == -1 ? wmax[t] : em[(size_t)t * V + tokens[j]]; };
-    std::vector<float> tr((size_t)T * J);
-    tr[0] = 0.f;
-    for (int t = 1; t < T; ++t) tr[(size_t)t * J] = tr[(size_t)(t - 1) * J] + em[(size_t)t * V + blank];
-    for (int j = 1; j < J; ++j) tr[j] = -inf;
-    if (J > 1) for (int t = std::max(0, T - (J - 1)); t < T; ++t) tr[(size_t)t * J] = inf;
-    for (int t = 0; t + 1 < T; ++t) {
-        const float* cur = &tr[(size_t)t * J];
-        float* nxt = &tr[(size_t)(t + 1) * J];
-        const float b = em[(size_t)t * V + blank];
-        for (int j = 1; j < J; ++j) {
-            const float stay = cur[j] + b, move = cur[j - 1] + lp(t, j);
-            nxt[j] = stay > move ? stay : move;               // max; a NaN (inf - inf) cannot arise: -inf only meets finite terms
-        }
-    }
-    int t = T - 1, j = J - 1, n = 0;
-    auto put = [&](int jj, int tt, float p) { token_index[tt] = jj; score[tt] = expf(p); ++n; };
-    put(j, t, em[(size_t)t * V + blank]);
-    while (j > 0) {
-        if (t <= 0) return MW_ERR_STATE;                       // fewer frames than tokens: no path
-        const float p_stay = em[(size_t)(t - 1) * V + blank], p_change = lp(t - 1, j);
-        const float stayed = tr[(size_t)(t - 1) * J + j] + p_stay, changed = tr[(size_t)(t - 1) * J + j - 1] + p_change;
-        --t;
-        const bool ch = changed > stayed;
-        if (ch) --j;
-        put(j, t, ch ? p_change : p_stay);
-    }
-    while (t > 0) { put(j, t - 1, em[(size_t)(t - 1) * V + blank]); --t; }
-    return n == T ? MW_OK : MW_ERR_STATE;
+    return path_search(b.data(), lp.data(), T, J, J, token_index, score);
+}
+
+// One segment end to end: the acoustic model, then the search, with only the columns the search reads (the blank and
+// the segment's tokens: [T][1 + n_tokens] instead of [T][vocab]) gathered on the GPU and brought to the host through
+// a pinned buffer.
+extern "C" int mw_align_segment(mw_aligner* a, const float* pcm, int64_t n_samples, const int32_t* tokens, int32_t n_tokens, int32_t blank_id,
+                                int32_t* token_index, float* score, int32_t* n_frames) {
+    if (!a) return MW_ERR_ARG;
+    if (!pcm || !tokens || !token_index || !score || !n_frames) return afail(a, MW_ERR_ARG, "mw_align_segment: null argument");
+    const mw_align_desc& d = a->d;
+    if (n_tokens < 1 || n_tokens > kMaxSegmentTokens) return afail(a, MW_ERR_ARG, "mw_align_segment: n_tokens must be in 1.." + std::to_string(kMaxSegmentTokens));
+    if (blank_id < 0 || blank_id >= d.vocab) return afail(a, MW_ERR_ARG, "mw_align_segment: blank_id outside the vocabulary");
+    for (int j = 0; j < n_tokens; ++j)
+        if (tokens[j] < -1 || tokens[j] >= d.vocab) return afail(a, MW_ERR_ARG, "mw_align_segment: token id outside the vocabulary");
+    int T = 0;
+    if (int r = run_model(a, pcm, n_samples, &T, "mw_align_segment")) return r;
+    hipStream_t s = a->stream;
+    const int ld = n_tokens + 1;
+    ACHK(hipMemcpyAsync(a->tok_dev, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice, s));
+    launch_ctc_gather(a->logits, T, a->vpad, d.vocab, a->tok_dev, n_tokens, blank_id, a->gath_dev, s);
+    ACHK(hipGetLastError());
+    ACHK(hipMemcpyAsync(a->gath_host, a->gath_dev, (size_t)T * ld * 4, hipMemcpyDeviceToHost, s));
+    ACHK(hipStreamSynchronize(s));
+    *n_frames = T;
+    // column 0 of the gathered rows is the blank: copy it out so that the search reads two plain arrays
+    std::vector<float> blank(T);
+    for (int t = 0; t < T; ++t) blank[t] = a->gath_host[(size_t)t * ld];
+    const int r = path_search(blank.data(), a->gath_host + 1, T, n_tokens, ld, token_index, score);
+    if (r == MW_ERR_STATE) a->err = "mw_align_segment: no path (fewer frames than tokens)";
+    return r;
 }

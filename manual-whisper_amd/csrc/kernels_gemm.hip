@@ -371,6 +371,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     constexpr int BM = MI * 32;
     constexpr int STAGE = (BM + BN) * BK;                        // halfs per buffer: A tile then W tile
     extern __shared__ __attribute__((aligned(16))) f16 lds[];   // [2][STAGE]
+    if (gridDim.y > 1) {                                        // grouped launch: blockIdx.y picks the product
+        const long g = blockIdx.y;
+        p.A += g * p.a_group_stride;
+        p.W += g * p.w_group_stride;
+        if (p.bias) p.bias += g * p.N;
+        p.C = p.out_mode == OUT_RESID_F32 ? static_cast<void*>(reinterpret_cast<float*>(p.C) + g * p.c_group_stride)
+                                          : static_cast<void*>(reinterpret_cast<f16*>(p.C) + g * p.c_group_stride);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -530,7 +538,7 @@ void launch_t(const GemmParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MI, GLDS, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     const int nt = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_kernel<MI, GLDS, F8>), dim3(nt), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_kernel<MI, GLDS, F8>), dim3(nt, p.groups > 1 ? p.groups : 1), dim3(256), lds, s, p);
 }
 
 // ------------------------------------------------------------------ 256x256x64 tile, 8 waves
@@ -820,6 +828,7 @@ void launch_gemm(const GemmParams& p0, hipStream_t s) {
     const int nk = p.K / BK;
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (p.K % BK != 0) launch_t<4, false>(p, s);
+    else if (p.groups > 1) launch_t<4, true>(p, s);                  // grouped products: the 128x128 form only
     else if (!no256 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256 && p.N % 8 == 0) launch_256<false>(p, s);
     else launch_t<4, true>(p, s);
 }

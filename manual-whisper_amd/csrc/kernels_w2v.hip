@@ -155,7 +155,31 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(float* __restrict
     for (int i = tid; i < V; i += 256) zr[i] -= lse;
 }
 
+// One workgroup per row: the best non-blank entry (for wildcard tokens), then the gather.
+__global__ __launch_bounds__(256) void ctc_gather_kernel(const float* __restrict__ z, int ld, int V, const int32_t* __restrict__ tokens, int J,
+                                                         int blank, float* __restrict__ out) {
+    __shared__ float red[4];
+    const float* zr = z + (long)blockIdx.x * ld;
+    float* o = out + (long)blockIdx.x * (J + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -3.0e38f;
+    for (int i = tid; i < V; i += 256) if (i != blank) m = fmaxf(m, zr[i]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (tid == 0) o[0] = zr[blank];
+    for (int j = tid; j < J; j += 256) {
+        const int t = tokens[j];
+        o[1 + j] = t < 0 ? m : zr[t];
+    }
+}
+
 }  // namespace
+
+void launch_ctc_gather(const float* z, int rows, int ld, int V, const int32_t* tokens, int J, int blank, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(ctc_gather_kernel, dim3(rows), dim3(256), 0, s, z, ld, V, tokens, J, blank, out);
+}
 
 void launch_w2v_conv0(const float* x, long n, const float* w, const float* b, const float* g, const float* beta, f16* out, int T0, int C,
                       int K0, int S0, hipStream_t s) {

@@ -67,6 +67,10 @@ struct GemmParams {
     int f8; const float* a_scale; const float* w_scale;
     // OUT_KV_SPLIT8 (f8 products only): k, v as e4m3 codes [B][H][T][64] with one scale per (b, h, t) row of 64
     uint8_t* k8; uint8_t* v8; float* ks; float* vs;
+    // groups > 1 (fp16 operands, OUT_F16 / OUT_RESID_F32 only): that many independent products of one shape in ONE
+    // launch; group g reads A + g * a_group_stride and W + g * w_group_stride (elements), bias + g * N, and writes
+    // C + g * c_group_stride (elements of C's type).  A grouped convolution as GEMMs over a group-major buffer.
+    int groups; long a_group_stride, w_group_stride, c_group_stride;
 };
 void launch_gemm(const GemmParams& p, hipStream_t s);
 
@@ -226,5 +230,7 @@ void launch_ln16(f16* x, const float* g, const float* b, int rows, int D, float 
 void launch_w2v_pos_pack(const float* x, f16* pack, int T, int D, int G, int K, hipStream_t s);
 // rows of z [rows][ld]: z[r][0..V) -= logsumexp(z[r][0..V))
 void launch_log_softmax_rows(float* z, int rows, int ld, int V, hipStream_t s);
+// out [rows][1 + J]: column 0 = z[r][blank], column 1 + j = z[r][tokens[j]], or for tokens[j] == -1 the largest z[r][v], v != blank
+void launch_ctc_gather(const float* z, int rows, int ld, int V, const int32_t* tokens, int J, int blank, float* out, hipStream_t s);
 
 }  // namespace mw

@@ -251,6 +251,25 @@ def test_gpu_concurrent_segments_on_forked_workspaces(micro_aligner):
 
 
 @pytest.mark.gpu
+def test_gpu_segment_path_equals_emissions_then_search(micro_aligner):
+    """mw_align_segment (columns gathered on the GPU, search on the host) against mw_align_emissions + mw_align_path,
+    with wildcards, a single token, and more tokens than frames."""
+    wave = _wave("a", 19200)
+    em = micro_aligner.emissions(wave)
+    for tokens in ([5, 9, -1, 7, 7, 30, -1], [12], list(range(1, 40)) + [-1] * 10, [3] * 70):
+        want = al.ctc_path(em, tokens, 0)
+        got, n = micro_aligner.segment_path(wave, tokens, 0)
+        assert n == em.shape[0]
+        if want is None:
+            assert got is None
+            continue
+        assert [(p.token_index, p.time_index) for p in got] == [(p.token_index, p.time_index) for p in want]
+        assert [p.score for p in got] == pytest.approx([p.score for p in want], rel=1e-6)
+    with pytest.raises(mw.EngineError, match="outside the vocabulary"):
+        micro_aligner.segment_path(wave, [40], 0)
+
+
+@pytest.mark.gpu
 def test_gpu_argument_errors(micro_aligner, micro_weights):
     with pytest.raises(mw.EngineError, match="max_samples"):
         micro_aligner.emissions(np.zeros(16000 * 4 + 1, np.float32))
