@@ -407,11 +407,21 @@ def main(argv=None):
             "bytes_per_layer": gv_bytes, "avg_layer_us": round(gv_ms * 1e3, 2), "traffic": None}
         # the timed region as a whole (engines overlapped): algorithmic HBM bytes and MFMA flops of all steps over the wall time
         sr = out["stage_roofline"]
-        hb = sr["algorithmic_hbm_bytes_per_step"] * world * args.steps / elapsed / 1e9
+        step_bytes = sr["algorithmic_hbm_bytes_per_step"]
+        if grouped:     # a decode group streams the decoder weights once per token for all its steps' sequences
+            n_seq = batch * args.group
+            step_bytes = (sr["algorithmic_hbm_bytes_per_step"] - decode_bytes(dims, batch, len(opts.prompt), NEW_TOKENS, 1 if args.weights == "fp8" else 2, args.kv == "fp8")
+                          + decode_bytes(dims, n_seq, len(opts.prompt), NEW_TOKENS, 1 if args.weights == "fp8" else 2, args.kv == "fp8") / args.group)
+        step_floor_ms = step_bytes / (HBM_PEAK_GBS * 1e6) + sr["algorithmic_flop_per_step"] / (MFMA_F16_PEAK_TFLOPS * 1e9)
+        hb = step_bytes * world * args.steps / elapsed / 1e9
         fl = sr["algorithmic_flop_per_step"] * world * args.steps / elapsed / 1e12
         out["whole_run"] = {"hbm_GBps_per_gpu": round(hb / world, 1), "hbm_frac": round(hb / world / HBM_PEAK_GBS, 4),
                             "mfma_TFLOPs_per_gpu": round(fl / world, 1), "mfma_frac": round(fl / world / MFMA_F16_PEAK_TFLOPS, 4),
-                            "step_floor_over_step": round(sr["sum_of_stage_floors_ms"] / (elapsed / args.steps * 1e3), 4)}
+                            "algorithmic_hbm_bytes_per_step": int(step_bytes), "step_floor_ms": round(step_floor_ms, 2),
+                            "step_floor_over_step": round(step_floor_ms / (elapsed / args.steps * 1e3), 4)}
+        if grouped:
+            out["whole_run"]["note"] = (f"bytes of a step as this arrangement moves them: decoder weights once per token per group of {args.group} steps "
+                                        "(stage_roofline prices one step decoding alone, weights streamed for its 16 sequences)")
         if group_solo is not None:
             out["stage_roofline"]["decode_group"] = group_solo
         if grouped:
