@@ -6,8 +6,9 @@ Environment (reference transcribe.py:30-36 plus this engine's own knobs):
   BATCH_SIZE     chunks per engine call (default 16 here; the reference's CPU default is 4)
   WHISPER_MODEL  model size / local checkpoint directory / synthetic:<size> (default large-v3)
   MW_MODEL_DIR   where model-size names are looked up
-  MW_ENGINES     engines in flight on the GPU (default 3)
-  MW_COALESCE    batches of BATCH_SIZE chunks joined per engine pass (default 8: passes of up to 128 chunks)
+  MW_ARRANGE     grouped (default): encoder halves of BATCH_SIZE chunks on MW_ENCODERS engines (default 2), greedy decoding
+                 of up to MW_GROUP batches at once (default 7) on MW_DECODERS engines (default 3), sized to the recording;
+                 coalesced: MW_ENGINES engines (default 3) that each run whole passes of MW_COALESCE batches (default 8)
   MW_DTYPE       float16 (default) or float8 (e4m3 Linear weights quantised at load)
   MW_SEGMENT_FILTER  1: clean up with the web service's rules instead (reference web/api/lib/processor.js:52-113:
                  filler noise dropped, neighbours merged; the JSON gains cleanup_stats and quality_report as in
@@ -34,6 +35,7 @@ BATCH_SIZE = int(os.environ.get("BATCH_SIZE", "16"))
 COMPUTE_TYPE = os.environ.get("MW_DTYPE", "float16")
 MODEL_SIZE = os.environ.get("WHISPER_MODEL", "large-v3")
 COALESCE = max(1, int(os.environ.get("MW_COALESCE", "8")))
+ARRANGE = os.environ.get("MW_ARRANGE", "grouped")
 HF_TOKEN = os.environ.get("HF_TOKEN")
 
 # reference transcribe.py:39-46
@@ -57,8 +59,10 @@ def transcribe_audio(audio_file, hf_token=None):
     say(f"📝 加载 Whisper {MODEL_SIZE} 模型...")
     model = load_model(MODEL_SIZE, DEVICE, device_index=local_rank, compute_type=COMPUTE_TYPE, language="zh",
                        asr_options={"initial_prompt": INITIAL_PROMPT}, vad_options=VAD_OPTIONS,
-                       max_batch=min(128, max(1, BATCH_SIZE) * COALESCE), n_engines=int(os.environ.get("MW_ENGINES", "3")),
-                       coalesce=COALESCE)
+                       max_batch=max(1, BATCH_SIZE) if ARRANGE == "grouped" else min(128, max(1, BATCH_SIZE) * COALESCE),
+                       n_engines=int(os.environ.get("MW_ENGINES", "3")), coalesce=COALESCE, arrangement=ARRANGE,
+                       group=int(os.environ.get("MW_GROUP", "7")), n_encoders=int(os.environ.get("MW_ENCODERS", "2")),
+                       n_decoders=int(os.environ.get("MW_DECODERS", "3")))
     say(f"   模型加载耗时: {time.time() - t:.1f}s")
     say("🔊 加载音频...")
     audio = load_audio(audio_file)

@@ -31,7 +31,7 @@ import numpy as np
 from .decode_options import DecodeOptions, synthetic_options, whisper_options
 from .dims import CHUNK_SAMPLES, MODELS, SAMPLE_RATE, WhisperDims, get_dims
 from .engine import Engine, EngineError
-from .scheduler import EnginePool, batches_of, split_chunks
+from .scheduler import EnginePool, GroupedPool, batches_of, split_chunks
 
 _GPU_NAMES = ("cuda", "hip", "gpu", "rocm")
 _FP16_NAMES = ("float16", "fp16", "half", "default")
@@ -65,19 +65,62 @@ class Model:
     def __init__(self, engine: Engine, dims: WhisperDims, language: str, tokenizer=None,
                  initial_prompt: Optional[str] = None, vad_options: Optional[dict] = None,
                  synthetic: bool = False, max_new: int = 224, n_engines: int = 1, beam_size: int = 1, patience: float = 1.0,
-                 coalesce: int = 1):
+                 coalesce: int = 1, arrangement: str = "coalesced", group: int = 7, n_encoders: int = 2, n_decoders: int = 3):
         self.engine, self.dims, self.language = engine, dims, language
         self.tokenizer, self.initial_prompt = tokenizer, initial_prompt
         self.vad_options = dict(vad_options or {})
         self.synthetic, self.max_new = synthetic, max_new
         if beam_size < 1 or beam_size > engine.max_batch:
             raise EngineError(f"beam_size={beam_size} does not fit max_batch={engine.max_batch}")
+        if arrangement not in ("grouped", "coalesced"):
+            raise EngineError(f"arrangement={arrangement!r}: 'grouped' or 'coalesced'")
         self.beam_size, self.patience = int(beam_size), float(patience)
-        # batches of `batch_size` chunks joined per engine pass (bounded by max_batch): chunks are independent, and
-        # one pass over 64 streams the decoder weights once where four passes over 16 stream them four times
+        # "grouped" (greedy decoding only): encoder passes of `batch_size` chunks on `n_encoders` engines, the greedy
+        # loop over up to `group` such batches at once on `n_decoders` engines (scheduler.GroupedPool), sized to the job
+        # at the first call.  "coalesced" (and beam search): `n_engines` engines that each run whole passes of up to
+        # `coalesce` batches (scheduler.EnginePool).
+        self.grouped = arrangement == "grouped" and self.beam_size == 1
+        self.group, self.n_encoders, self.n_decoders = max(1, int(group)), max(1, int(n_encoders)), max(1, int(n_decoders))
         self.coalesce = max(1, int(coalesce))
-        self.pool = EnginePool(engine, n_engines, self.beam_size, self.patience)
+        self.n_engines = n_engines
+        self.pool = None                    # built at the first call: its engines are sized to what the call needs
+        self._pool_key = None
         self._opts_for = None
+
+    def _pool_for(self, n_chunks: int, batch_size: int):
+        """The engine pool for a job of `n_chunks` chunks in batches of `batch_size`; kept between calls and rebuilt
+        only when a call needs more than the pool at hand (more chunks per batch, larger groups, more engines)."""
+        if not self.grouped:
+            if self.pool is None:
+                self.pool = EnginePool(self.engine, self.n_engines, self.beam_size, self.patience)
+                self._pool_key = ("coalesced",)
+            return self.pool
+        n_batches = max(1, -(-n_chunks // batch_size))
+        group = max(1, min(self.group, n_batches, 512 // batch_size))
+        n_groups = -(-n_batches // group)
+        need = (batch_size, group, min(self.n_encoders, n_batches), min(self.n_decoders, n_groups))
+        have = self._pool_key
+        if self.pool is not None and have[0] == "grouped" and all(h >= n for h, n in zip(have[1:], need)):
+            return self.pool
+        if self.pool is not None:
+            self._close_pool()
+            need = tuple(max(h, n) for h, n in zip(have[1:], need)) if have[0] == "grouped" else need
+        self.pool = GroupedPool(self.engine, need[0], need[1], need[2], need[3])
+        self._pool_key = ("grouped",) + need
+        self._opts_for = None
+        return self.pool
+
+    def _close_pool(self):
+        """Close the pool's engines but keep the root engine (it owns the weights)."""
+        pool, self.pool = self.pool, None
+        if pool is None:
+            return
+        for ex in (getattr(pool, "_pool", None), getattr(pool, "_enc_pool", None), getattr(pool, "_dec_pool", None)):
+            if ex is not None:
+                ex.shutdown(wait=True)
+        for e in reversed(pool.engines):
+            if e is not self.engine:
+                e.close()
 
     # -- decoding rules ---------------------------------------------------------------
     def decode_options(self, language: str) -> DecodeOptions:
@@ -133,18 +176,24 @@ class Model:
         count follows its duration, so passes are filled with windows of like duration, longest first (chunks are
         independent: the ids do not change)."""
         language = language or self.language
-        if self._opts_for != language:
-            self.pool.set_decode_options(self.decode_options(language))
-            self._opts_for = language
         n = len(chunks)
+        if n == 0:
+            return []
+        if self.grouped:
+            bs = max(1, min(int(batch_size), 512))
+        else:
+            bs = max(1, min(int(batch_size) * self.coalesce, self.engine.max_batch // self.beam_size))
+        pool = self._pool_for(n, bs)
+        if self._opts_for != language:
+            pool.set_decode_options(self.decode_options(language))
+            self._opts_for = language
         order = list(range(n))
         if durations is not None:
             order = sorted(order, key=lambda i: -durations[i])        # stable: equal durations keep their order
         if order != list(range(n)):
             chunks = chunks[order]
-        bs = max(1, min(int(batch_size) * self.coalesce, self.engine.max_batch // self.beam_size))
         got = []
-        for ids, lens in self.pool.map([chunks[a:b] for a, b in batches_of(n, bs)]):
+        for ids, lens in pool.map([chunks[a:b] for a, b in batches_of(n, bs)]):
             got.extend(ids[i, : lens[i]].copy() for i in range(ids.shape[0]))
         out = [None] * n
         for rank, i in enumerate(order):
@@ -164,25 +213,31 @@ class Model:
         return {"segments": segments, "language": language}
 
     def close(self):
-        self.pool.close()
+        self._close_pool()
+        self.engine.close()
 
 
 def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, compute_type: str = "float16",
                asr_options: Optional[dict] = None, language: Optional[str] = None, vad_options: Optional[dict] = None,
                task: str = "transcribe", max_batch: Optional[int] = None, n_engines: int = 2, coalesce: int = 4,
+               arrangement: str = "grouped", group: int = 7, n_encoders: int = 2, n_decoders: int = 3,
                **_ignored) -> Model:
     """Build an engine on GPU ``device_index``.
 
     whisper_arch: a local directory in Hugging Face layout, a model size whose directory is
     ``$MW_MODEL_DIR/<size>``, or ``synthetic:<size>``.
-    The engine's own knobs have defaults a caller of the reference's signature never needs to touch: two engines
-    in flight, batches of ``transcribe(batch_size=...)`` chunks joined four to a pass, passes of up to
-    ``max_batch`` chunks (default 16 * coalesce; at most 128).  large-v3 takes about 0.4 GB of caches and
-    workspaces per chunk of ``max_batch`` and engine.
+    The engine's own knobs have defaults a caller of the reference's signature never needs to touch.
+    ``arrangement="grouped"`` (greedy decoding, the default): the encoder half of every batch of
+    ``transcribe(batch_size=...)`` chunks runs on one of ``n_encoders`` engines, and ``n_decoders`` engines each run
+    the greedy loop over up to ``group`` such batches at once, so the decoder weights stream once per token per
+    group; the engines are created at the first call, sized to the recording (a decode engine takes about 0.32 GB
+    per chunk at large-v3).  ``arrangement="coalesced"`` (always used for beam search): ``n_engines`` engines in
+    flight that each run whole passes of ``coalesce`` batches, ``max_batch`` chunks at most (default 16 * coalesce).
     """
     coalesce = max(1, int(coalesce))
+    beam = int((asr_options or {}).get("beam_size", 1))
     if max_batch is None:
-        max_batch = min(128, 16 * coalesce)
+        max_batch = 16 if (arrangement == "grouped" and beam == 1) else min(128, 16 * coalesce)
     if device not in _GPU_NAMES:
         raise EngineError(f"device={device!r}: this engine runs on an MI355X GPU only (use 'cuda'); there is no CPU path")
     if compute_type not in _FP16_NAMES + _FP8_NAMES:
@@ -225,4 +280,5 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
     del weights
     return Model(engine, dims, language or "zh", tokenizer, asr_options.get("initial_prompt"), vad_options,
                  synthetic=synthetic, max_new=int(asr_options.get("max_new_tokens", 224)), n_engines=n_engines,
-                 beam_size=int(asr_options.get("beam_size", 1)), patience=float(asr_options.get("patience", 1.0)), coalesce=coalesce)
+                 beam_size=int(asr_options.get("beam_size", 1)), patience=float(asr_options.get("patience", 1.0)), coalesce=coalesce,
+                 arrangement=arrangement, group=group, n_encoders=n_encoders, n_decoders=n_decoders)

@@ -493,7 +493,7 @@ def test_model_coalesces_batches_without_changing_ids():
     res = {}
     for coalesce in (1, 4):
         model = mw.load_model("synthetic:micro", "cuda", asr_options={"max_new_tokens": 8}, max_batch=16 * coalesce,
-                              coalesce=coalesce)
+                              coalesce=coalesce, arrangement="coalesced")
         try:
             res[coalesce] = model.transcribe(audio, batch_size=16, return_tokens=True)
         finally:
@@ -501,6 +501,33 @@ def test_model_coalesces_batches_without_changing_ids():
     assert len(res[1]["segments"]) == 40
     assert [s["tokens"] for s in res[1]["segments"]] == [s["tokens"] for s in res[4]["segments"]]
     assert res[4]["segments"][-1]["end"] == pytest.approx(30 * 39 + 7)
+
+
+def test_model_default_arrangement_is_grouped_and_sized_to_the_job():
+    """load_model's default: encoder halves of batch_size chunks, decoding in groups (scheduler.GroupedPool), the
+    engines created at the first call and sized to it; a larger later call rebuilds them.  Segments are those of
+    plain passes of 16 (up to the near-tie tolerance of the projection kernels that groups beyond 32 sequences use)."""
+    from manual_whisper_amd.scheduler import GroupedPool
+    audio = synth.make_pcm_np(40, seed=77).reshape(-1)[: 16000 * (30 * 39 + 7)]      # 40 chunks, the last one 7 s
+    plain = mw.load_model("synthetic:micro", "cuda", asr_options={"max_new_tokens": 8}, max_batch=16, coalesce=1, n_engines=1,
+                          arrangement="coalesced")
+    model = mw.load_model("synthetic:micro", "cuda", asr_options={"max_new_tokens": 8}, group=2, n_decoders=2)
+    try:
+        want = plain.transcribe(audio, batch_size=16, return_tokens=True)
+        assert model.pool is None                                   # nothing allocated before the first call
+        small = model.transcribe(audio[: 16000 * 45], batch_size=16, return_tokens=True)     # 2 chunks: one batch, one group
+        assert isinstance(model.pool, GroupedPool) and model._pool_key == ("grouped", 16, 1, 1, 1)
+        assert [s["tokens"] for s in small["segments"]][:1] == [s["tokens"] for s in want["segments"]][:1]
+        got = model.transcribe(audio, batch_size=16, return_tokens=True)                      # 3 batches: groups of 2 and 1
+        assert model._pool_key == ("grouped", 16, 2, 2, 2)
+        assert [(s["start"], s["end"]) for s in got["segments"]] == [(s["start"], s["end"]) for s in want["segments"]]
+        same = sum(a["tokens"] == b["tokens"] for a, b in zip(got["segments"], want["segments"]))
+        assert same >= 40 - 3 and all(a["tokens"][:3] == b["tokens"][:3] for a, b in zip(got["segments"], want["segments"]))
+        again = model.transcribe(audio[: 16000 * 45], batch_size=16, return_tokens=True)     # a smaller job reuses the pool
+        assert model._pool_key == ("grouped", 16, 2, 2, 2) and again == small
+    finally:
+        model.close()
+        plain.close()
 
 
 def test_grouped_pool_encodes_in_batches_and_decodes_in_groups():
