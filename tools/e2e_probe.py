@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Development aid: where the time of Model.transcribe goes on a long recording (windows, engine passes, text),
-first call (captures the decode graphs) and second call.  Usage: python tools/e2e_probe.py [minutes] [engines] [coalesce]"""
+first call (creates the engines, captures the decode graphs) and later calls.
+Usage: python tools/e2e_probe.py [minutes] [engines] [coalesce]; E2E_ARRANGE=grouped (default) | coalesced"""
 import os
 import sys
 import time
@@ -19,8 +20,9 @@ rng = np.random.default_rng(0)
 audio = (0.1 * rng.standard_normal(minutes * 60 * 16000)).astype(np.float32)
 t = time.perf_counter()
 model = mw.load_model("synthetic:large-v3", "cuda", compute_type=os.environ.get("MW_DTYPE", "float16"), language="zh",
-                      asr_options={"max_new_tokens": 128}, vad_options=vad, max_batch=min(128, 16 * coalesce),
-                      n_engines=engines, coalesce=coalesce)
+                      asr_options={"max_new_tokens": 128}, vad_options=vad,
+                      max_batch=16 if os.environ.get("E2E_ARRANGE", "grouped") == "grouped" else min(128, 16 * coalesce),
+                      n_engines=engines, coalesce=coalesce, arrangement=os.environ.get("E2E_ARRANGE", "grouped"))
 print(f"load {time.perf_counter() - t:.2f} s", flush=True)
 for call in (1, 2, 3):
     t0 = time.perf_counter()
