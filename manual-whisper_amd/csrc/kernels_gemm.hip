@@ -552,7 +552,9 @@ void launch_t(const GemmParams& p, hipStream_t s) {
 // vmcnt) is described at the `ktile` lambda.  Measured with in-kernel stamps (-DMW_GEMM_STAMPS): 1.48 us per K-tile
 // of 64, where the MFMAs alone take 1.05 us at the ~1.95 GHz the chip holds under this load: a wave's read
 // section (24 ds_read_b128 and 8 LDS-DMA instructions per K-tile, the latter 60-185 cycles each to issue) is as
-// long as its partner's MFMA section.  Four phases of 16 MFMAs (twice the barriers) were 2 % slower.
+// long as its partner's MFMA section.  Four phases of 16 MFMAs (twice the barriers) were 2 % slower.  Issuing the
+// fp16 form's DMA like the fp8 form's (matrix base in scalar registers, one 32-bit lane offset per instruction) took
+// 24 registers less and exactly the same time: the address form is not what a read section costs.
 constexpr int kHalfSlot = 128 * BK;          // halfs per half-tile slot
 enum { SLOT_A0 = 0, SLOT_A1 = 1, SLOT_B0 = 2, SLOT_B1 = 3 };
 
