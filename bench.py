@@ -160,6 +160,32 @@ def side_run(dims, opts, dev, local_rank, batch, engines, weights="f16", kv="f16
             "ms_per_16_chunks": round(dt / (steps * batch / 16) * 1e3, 3)}
 
 
+def grouped_side_run(dims, opts, dev, local_rank, batch, group, n_enc, n_dec, weights="f16", kv="f16", steps=14):
+    """A second measurement in the headline's arrangement (scheduler.GroupedPool): `steps` batches of `batch` chunks,
+    encoder halves on `n_enc` engines, greedy decoding of up to `group` batches at once on `n_dec` engines."""
+    import torch
+    from manual_whisper_amd import synth
+    from manual_whisper_amd.engine import Engine
+    from manual_whisper_amd.scheduler import GroupedPool
+    eng = Engine(dims, device=local_rank, max_batch=batch, weight_format=weights, kv_format=kv)
+    eng.load_weights(synth.make_weights_torch(dims, seed=1234, device=dev))
+    eng.set_decode_options(opts)
+    pool = GroupedPool(eng, batch, group, n_enc, n_dec)
+    pool.set_decode_options(opts)
+    pcms = [synth.make_pcm_torch(batch, seed=5000 + i, device=dev) for i in range(2)]
+    torch.cuda.synchronize()
+    pool.map([pcms[0]] * (group * n_dec))               # every decode engine captures its graphs once
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pool.map([pcms[i % 2] for i in range(steps)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pool.close()
+    torch.cuda.empty_cache()
+    return {"value": round(steps * batch * 30.0 / dt, 2), "unit": "audio-seconds/second", "steps_timed": steps,
+            "ms_per_step": round(dt / steps * 1e3, 3), "ms_per_16_chunks": round(dt / (steps * batch / 16) * 1e3, 3)}
+
+
 def coalesced_run(args, dims, opts, dev, local_rank):
     """The same workload with the scheduler coalescing several batches of 16 into one engine pass: the decode
     GEMVs then stream every weight once for all of them (groups of 16 sequences inside each launch)."""
@@ -173,11 +199,15 @@ def coalesced_run(args, dims, opts, dev, local_rank):
 def fp8_b32_run(dims, opts, dev, local_rank):
     """BASELINE configs[4]'s per-GPU shape beside the fp16 headline: e4m3 Linear weights, 32 chunks per pass.
     The e4m3 cross-attention K/V cache is this build's own extension, not part of configs[4]: reported apart."""
-    out = {"workload": "whisper-large-v3, fp8 (e4m3) Linear weights with fp8 MFMA in the encoder, batch=32x30 s chunks per pass, greedy, "
-                       f"{len(opts.prompt)} prompt + {opts.max_new} sampled tokens per chunk (EOT suppressed), 3 engines in flight, 1 GPU",
-           "fp8_weights": side_run(dims, opts, dev, local_rank, 32, 3, "fp8", "f16"),
-           "fp8_weights_and_fp8_cross_kv_cache": side_run(dims, opts, dev, local_rank, 32, 3, "fp8", "fp8")}
+    out = {"workload": "whisper-large-v3, fp8 (e4m3) Linear weights with fp8 MFMA in the encoder, batch=32x30 s chunks per step, greedy, "
+                       f"{len(opts.prompt)} prompt + {opts.max_new} sampled tokens per chunk (EOT suppressed), 1 GPU; the headline's arrangement: "
+                       "every step's encoder half on its own 32 chunks (2 encoder engines), greedy loop over up to 7 steps' 224 sequences "
+                       "at once (2 decode engines), 14 steps timed",
+           "fp8_weights": grouped_side_run(dims, opts, dev, local_rank, 32, 7, 2, 2, "fp8", "f16"),
+           "fp8_weights_and_fp8_cross_kv_cache": grouped_side_run(dims, opts, dev, local_rank, 32, 7, 2, 2, "fp8", "fp8")}
     out["fp8_weights_and_fp8_cross_kv_cache"]["note"] = "the e4m3 cross K/V cache is an extension of this build, outside configs[4]"
+    out["fp8_weights"]["whole_passes"] = side_run(dims, opts, dev, local_rank, 32, 3, "fp8", "f16")
+    out["fp8_weights"]["whole_passes"]["workload"] = "3 engines in flight that each run whole passes of 32 chunks (no decode groups)"
     return out
 
 
@@ -426,6 +456,12 @@ def main(argv=None):
             out["stage_roofline"]["decode_group"] = group_solo
         if grouped:
             out["stage_ms_note"] = "decode: one group's loop (all its steps' sequences); the other stages: one step's 16 chunks"
+        # the side measurements build engines of their own: give the memory of this run's forks back first
+        # (the root engine stays: the CPU baseline compares its ids)
+        for e in reversed(pool.engines):
+            if e is not eng:
+                e.close()
+        torch.cuda.empty_cache()
         if world == 1 and args.also_batch > batch:
             out["coalesced"] = coalesced_run(args, dims, opts, dev, local_rank)
         if world == 1 and grouped and not args.no_ungrouped:
