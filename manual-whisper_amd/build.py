@@ -68,5 +68,25 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_gemm_check(force: bool = False, verbose: bool = True) -> str:
+    """tools/gemm_bench: a stand-alone program that runs launch_gemm (the encoder's matrix products, every fused
+    epilogue) against a naive GPU product; the GPU tests run it (tests/test_gpu_gemm.py).  Links the library's
+    own kernels_gemm.o."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "gemm_bench.hip")
+    exe = os.path.join(root, "tools", "gemm_bench")
+    obj = os.path.join(CSRC, "kernels_gemm.o")
+    if force or _stale(exe, [src, obj] + HEADERS):
+        hipcc = _hipcc()
+        tmp = os.path.join(root, "tools", "gemm_bench.o")
+        for cmd in ([hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-I", CSRC, "-c", src, "-o", tmp],
+                    [hipcc, f"--offload-arch={ARCH}", tmp, obj, "-o", exe]):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+    return exe
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv))
+    print(build_gemm_check(force="--force" in sys.argv))
