@@ -81,6 +81,7 @@ class Model:
         # `coalesce` batches (scheduler.EnginePool).
         self.grouped = arrangement == "grouped" and self.beam_size == 1
         self.group, self.n_encoders, self.n_decoders = max(1, int(group)), max(1, int(n_encoders)), max(1, int(n_decoders))
+        self.max_group_sequences = 128
         self.coalesce = max(1, int(coalesce))
         self.n_engines = n_engines
         self.pool = None                    # built at the first call: its engines are sized to what the call needs
@@ -96,7 +97,10 @@ class Model:
                 self._pool_key = ("coalesced",)
             return self.pool
         n_batches = max(1, -(-n_chunks // batch_size))
-        group = max(1, min(self.group, n_batches, 512 // batch_size))
+        # a decode engine holds its group's cross-attention K/V (0.25 GB per sequence at large-v3) and, like every
+        # engine, encoder-sized workspaces: groups are kept to `max_group_sequences` so that three of them fit beside
+        # the encoders whatever batch_size the caller picks
+        group = max(1, min(self.group, n_batches, max(1, self.max_group_sequences // batch_size)))
         n_groups = -(-n_batches // group)
         need = (batch_size, group, min(self.n_encoders, n_batches), min(self.n_decoders, n_groups))
         have = self._pool_key
@@ -180,7 +184,7 @@ class Model:
         if n == 0:
             return []
         if self.grouped:
-            bs = max(1, min(int(batch_size), 512))
+            bs = max(1, min(int(batch_size), self.max_group_sequences))
         else:
             bs = max(1, min(int(batch_size) * self.coalesce, self.engine.max_batch // self.beam_size))
         pool = self._pool_for(n, bs)
