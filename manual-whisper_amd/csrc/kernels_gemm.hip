@@ -554,7 +554,10 @@ void launch_t(const GemmParams& p, hipStream_t s) {
 // section (24 ds_read_b128 and 8 LDS-DMA instructions per K-tile, the latter 60-185 cycles each to issue) is as
 // long as its partner's MFMA section.  Four phases of 16 MFMAs (twice the barriers) were 2 % slower.  Issuing the
 // fp16 form's DMA like the fp8 form's (matrix base in scalar registers, one 32-bit lane offset per instruction) took
-// 24 registers less and exactly the same time: the address form is not what a read section costs.
+// 24 registers less and exactly the same time: the address form is not what a read section costs.  Timing builds
+// with parts removed (results meaningless), per K-tile: MFMAs and barriers alone 0.95-1.0 us, + LDS-DMA 1.16,
+// + LDS reads instead 1.36-1.48, everything 1.5-1.6; SQ_LDS_BANK_CONFLICT is 0 and the LDS array is busy 17 % of the
+// kernel (SQ_LDS_IDX_ACTIVE = 4 cycles per ds_read_b128), so the reads cost latency beside the MFMAs, not bandwidth.
 constexpr int kHalfSlot = 128 * BK;          // halfs per half-tile slot
 enum { SLOT_A0 = 0, SLOT_A1 = 1, SLOT_B0 = 2, SLOT_B1 = 3 };
 
