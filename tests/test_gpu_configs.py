@@ -133,6 +133,47 @@ def test_config3_large_v3_batch16_rows_vs_oracle(large):
     assert same >= 2
 
 
+def test_config3_large_v3_decode_group_rows_vs_oracle(large):
+    """The benchmark's decode shape: seven encoder passes of 16 chunks written into one decode engine's cache
+    (mw_encode_into), one greedy loop over the 112 sequences (the projections then run as gemm_dec_kernel, the
+    LayerNorms as launches of their own, the cross-attention as a launch of seven rounds).  4 of the 112 rows x 16
+    sampled tokens against the fp32 oracle, and the group's ids against the same chunks decoded 16 at a time."""
+    dims, eng, orc = large
+    n_new = 16
+    opts = synthetic_options(dims, max_new=n_new, suppress_eot=True)
+    eng.set_decode_options(opts)
+    pcm = synth.make_pcm_np(112, seed=909)
+    rows = [0, 37, 75, 111]
+    dec = eng.fork(112)
+    try:
+        dec.set_decode_options(opts)
+        for i in range(7):
+            eng.encode_into(pcm[16 * i: 16 * i + 16], dec, 16 * i)
+        dec.set_encoded(112)
+        ids, lens, logits = dec.decode_greedy(112, want_logits=True)        # logits [n_new][112][vocab]
+        assert (lens == n_new).all()
+        enc_ref = orc.encode(log_mel(pcm[rows], dims.n_mels))
+        wi, wl, wlog = orc.greedy(enc_ref, list(opts.prompt), n_new, opts.eot, opts.effective_suppress(), opts.begin_suppress,
+                                  return_logits=True)
+        assert_ids_match_up_to_ties(ids[rows], wi, orc.last_margins)
+        first_err = float(np.abs(logits[0][rows] - wlog[0]).max())
+        path_err = 0.0
+        for j, r in enumerate(rows):
+            diff = np.nonzero(ids[r] != wi[j])[0]
+            upto = int(diff[0]) + 1 if diff.size else n_new
+            path_err = max(path_err, float(np.abs(logits[:upto, r] - wlog[:upto, j]).max()))
+        same = int((ids[rows] == wi).all(axis=1).sum())
+        # the same chunks 16 at a time (fused-LayerNorm GEMV kernels: other summation order, so near-ties may part)
+        by16 = np.concatenate([eng.transcribe_batch(pcm[16 * i: 16 * i + 16])[0] for i in range(7)])
+        agree = int((by16 == ids).all(axis=1).sum())
+        print(f"decode group of 112, rows {rows}: first-position logits {first_err:.2e}, on-path logits {path_err:.2e}, "
+              f"{same}/4 rows identical to the oracle over {n_new} tokens, {agree}/112 identical to passes of 16")
+        assert first_err < LOGIT_ATOL and path_err < 2 * LOGIT_ATOL, (first_err, path_err)
+        assert same >= 2 and agree >= 100 and (by16[:, :3] == ids[:, :3]).all()
+    finally:
+        dec.close()
+
+
 def test_config3_large_v3_batch16_properties(large):
     """Batch 16 at full size: run-to-run identical, independent of batch position and batch size,
     identical from a forked engine."""
