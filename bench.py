@@ -297,7 +297,10 @@ def main(argv=None):
     from manual_whisper_amd.scheduler import EnginePool, GroupedPool
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MW_BENCH_REHEARSE=1: a rehearsal of the N > 1 path on a box with one GPU (every rank on GPU 0, the exchange over
+    # gloo from host memory); the line it prints is marked and is no measurement
+    rehearse = os.environ.get("MW_BENCH_REHEARSE") == "1"
+    local_rank = 0 if rehearse else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -306,7 +309,11 @@ def main(argv=None):
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if rehearse else dev        # where the tensors of the collectives live
 
     dims = mw.get_dims(args.model)
     opts = synthetic_options(dims, max_new=NEW_TOKENS, suppress_eot=True)
@@ -346,13 +353,13 @@ def main(argv=None):
     results = pool.map([pcms[(args.warmup + i) % len(pcms)] for i in range(args.steps)])
     if world > 1:       # one exchange of (length, ids) rows for everything this rank transcribed
         rows = np.concatenate([np.concatenate([lens[:, None], ids], axis=1) for ids, lens in results], axis=0)
-        rows_dev = torch.from_numpy(rows).to(dev)
-        gathered = torch.empty((world,) + tuple(rows_dev.shape), dtype=torch.int32, device=dev)
+        rows_dev = torch.from_numpy(rows).to(cdev)
+        gathered = torch.empty((world * rows_dev.shape[0], rows_dev.shape[1]), dtype=torch.int32, device=cdev)     # rank-major
         dist.all_gather_into_tensor(gathered, rows_dev)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     stage = {}
@@ -403,7 +410,7 @@ def main(argv=None):
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.weights == "f16" else "fp8 weights (e4m3) / f16 activations, fp8 MFMA for the encoder's LayerNorm-fed products",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearse else "synthetic; REHEARSAL: all ranks on one GPU, gloo exchange, not a measurement",
             "rtf": round(elapsed / audio_s, 6),
             "config": {"workload": f"whisper-{args.model} {'fp16' if args.weights == 'f16' else 'fp8 weights'}{' + fp8 cross K/V cache' if args.kv == 'fp8' else ''}, batch={batch}x30 s chunks per GPU, greedy, "
                                    f"{len(opts.prompt)} prompt + {NEW_TOKENS} sampled tokens per chunk (EOT suppressed), "

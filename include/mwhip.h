@@ -186,6 +186,29 @@ int mw_decode_forced(mw_ctx* ctx, int batch, const int32_t* tokens, int n, float
 int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience, int32_t* out_ids, int32_t* out_len,
                    float* out_avg_logprob, int32_t* hyp_ids, int32_t* hyp_len, float* hyp_sum_logprob);
 
+/* Sampling at a temperature over the encoder state of the last mw_encode(n_audio): the decodes of the temperature
+ * fallback (asr_options temperatures / best_of / compression_ratio_threshold / log_prob_threshold of
+ * whisperx.load_model, reference transcribe.py:107-113; the loop that walks the temperatures is host code, see
+ * fallback.py).  best_of (1..8) independent samples per recording, n_audio * best_of <= max_batch; every sampled
+ * token is drawn from softmax(logits / temperature) under the suppress rules of mw_set_decode_opts, as a Gumbel
+ * arg-max over counter-based uniforms of (seed, sequence, position, token id): the same arguments give the same
+ * ids.  temperature 0: the arg-max (greedy decoding with its log-probabilities).  A sample's score is the sum
+ * of log-softmax(logits) of its tokens, end-of-text included; the recording's result is the sample with the highest
+ * score per token.  active (optional, uint8 [n_audio], host memory): recordings with 0 are not decoded (length 0, no
+ * cross-attention reads), so that a fallback pass pays only for the windows that failed.
+ * out_ids int32 [n_audio][max_new] padded with eot; out_len int32 [n_audio]; out_avg_logprob float32 [n_audio] or
+ * NULL (score / (len + 1)).  Optional (NULL to skip): every sample, smp_ids int32 [n_audio][best_of][max_new],
+ * smp_len int32 [n_audio][best_of], smp_sum_logprob float32 [n_audio][best_of]; logits_out float32
+ * [max_new][n_audio*best_of][vocab] as in mw_decode_greedy (ended sequences are then not skipped). */
+int mw_decode_sample(mw_ctx* ctx, int n_audio, int best_of, float temperature, uint32_t seed, const uint8_t* active,
+                     int32_t* out_ids, int32_t* out_len, float* out_avg_logprob, int32_t* smp_ids, int32_t* smp_len,
+                     float* smp_sum_logprob, float* logits_out);
+
+/* The uniform in (0, 1) behind the draw of mw_decode_sample for sequence `sequence` (= recording * best_of + sample),
+ * sampled position `position` (0 = the first token after the prompt) and token id `token`: host code, no GPU needed.
+ * The token drawn at a position is argmax over the unsuppressed ids of logits[id] / temperature - log(-log(u(id))). */
+float mw_sample_uniform(uint32_t seed, uint32_t sequence, uint32_t position, uint32_t token);
+
 /* Stages 1-3 in one call: pcm float32 [batch][480000] -> ids. */
 int mw_transcribe_batch(mw_ctx* ctx, const float* pcm, int batch, int32_t* out_ids, int32_t* out_len);
 

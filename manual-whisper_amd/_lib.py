@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MW_LIB_PATH") or os.path.join(_HERE, "libmwhip.so")  
 # every symbol include/mwhip.h declares
 SYMBOLS = (
     "mw_create", "mw_fork", "mw_fork_sized", "mw_set_weight", "mw_finalize", "mw_set_decode_opts", "mw_destroy", "mw_last_error",
-    "mw_logmel", "mw_logmel_noalloc", "mw_encode", "mw_encode_into", "mw_set_encoded", "mw_decode_greedy", "mw_decode_beam", "mw_decode_forced", "mw_transcribe_batch",
+    "mw_logmel", "mw_logmel_noalloc", "mw_encode", "mw_encode_into", "mw_set_encoded", "mw_decode_greedy", "mw_decode_beam", "mw_decode_sample", "mw_sample_uniform", "mw_decode_forced", "mw_transcribe_batch",
     "mw_frame_energy_db", "mw_stage_ms", "mw_profile_cross_attention", "mw_profile_decode_gemvs", "mw_set_option", "mw_synchronize",
     "mw_align_frames", "mw_align_create", "mw_align_destroy", "mw_align_last_error", "mw_align_set_weight", "mw_align_finalize",
     "mw_align_emissions", "mw_align_fork", "mw_align_path", "mw_align_segment",
@@ -96,6 +96,9 @@ def load() -> C.CDLL:
     lib.mw_encode.argtypes = [vp, f32p, C.c_int, f32p]
     lib.mw_decode_greedy.argtypes = [vp, C.c_int, vp, vp, f32p]
     lib.mw_decode_beam.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, vp, f32p, vp, vp, f32p]
+    lib.mw_decode_sample.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_uint32, vp, vp, vp, f32p, vp, vp, f32p, f32p]
+    lib.mw_sample_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.mw_sample_uniform.restype = C.c_float
     lib.mw_decode_forced.argtypes = [vp, C.c_int, vp, C.c_int, f32p]
     lib.mw_transcribe_batch.argtypes = [vp, f32p, C.c_int, vp, vp]
     lib.mw_frame_energy_db.argtypes = [vp, f32p, C.c_int64, C.c_int, C.c_int, f32p, C.c_int64]
@@ -118,7 +121,7 @@ def load() -> C.CDLL:
     lib.mw_align_segment.argtypes = [vp, f32p, C.c_int64, vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
     lib.mw_align_path.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp]
     for name in SYMBOLS:
-        if name not in ("mw_destroy", "mw_last_error", "mw_align_destroy", "mw_align_last_error", "mw_align_frames"):
+        if name not in ("mw_destroy", "mw_last_error", "mw_align_destroy", "mw_align_last_error", "mw_align_frames", "mw_sample_uniform"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

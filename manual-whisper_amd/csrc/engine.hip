@@ -116,6 +116,11 @@ struct mw_ctx {
     int* bm_part_i = nullptr;
     int *bm_hist = nullptr, *bm_src_rows = nullptr, *bm_fin_tokens = nullptr, *bm_fin_len = nullptr, *bm_fin_count = nullptr,
         *bm_completed = nullptr;
+    // sampling at a temperature (allocated on first use)
+    SampleState* ss = nullptr;
+    float *sp_sum_lp = nullptr, *sp_part_m = nullptr, *sp_part_s = nullptr, *sp_part_v = nullptr, *sp_part_l = nullptr;
+    int* sp_part_i = nullptr;
+    uint8_t* sp_active = nullptr;
 
     // decode options
     std::vector<int32_t> prompt;
@@ -858,7 +863,8 @@ static void cross_attention(mw_ctx* ctx, int li, const f16* q, f16* out, int row
 
 // The end of a step: final LayerNorm (the same launch advances the position counter for the launches after
 // it), logits with the partial arg-max, token bookkeeping.
-static void enqueue_step_tail(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, const BeamParams* beam = nullptr) {
+static void enqueue_step_tail(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, const BeamParams* beam = nullptr,
+                              const SampleParams* samp = nullptr) {
     const mw_model_desc& d = ctx->d;
     const int D = d.d_model;
     hipStream_t s = ctx->stream;
@@ -873,6 +879,7 @@ static void enqueue_step_tail(mw_ctx* ctx, int B, bool want_logits, const Finali
         launch_gemv(p, s);
     }
     if (beam) launch_beam_step(*beam, s);
+    else if (samp) launch_sample_step(*samp, s);
     else launch_dec_finalize(fp, B, s);
 }
 
@@ -880,7 +887,7 @@ static void enqueue_step_tail(mw_ctx* ctx, int B, bool want_logits, const Finali
 // attention launches.  `parts`: kLayerGemv, kLayerAttn or both (the measurement entry points time them apart).
 enum { kLayerGemv = 1, kLayerAttn = 2 };
 static void enqueue_layer(mw_ctx* ctx, int li, int B, bool want_logits, const FinalizeParams& fp, int max_keys, const BeamParams* beam,
-                          int parts = kLayerGemv | kLayerAttn) {
+                          int parts = kLayerGemv | kLayerAttn, const SampleParams* samp = nullptr) {
     const mw_model_desc& d = ctx->d;
     const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, Tc = d.n_text_ctx;
     hipStream_t s = ctx->stream;
@@ -917,6 +924,8 @@ static void enqueue_layer(mw_ctx* ctx, int li, int B, bool want_logits, const Fi
     // (not when the caller asked for the logits of every position: those are then the model's own throughout)
     if (attn) {
         if (beam) cross_attention(ctx, li, ctx->dq, ctx->datt, B, beam->beam, 0, (ctx->skip_done && ctx->can_end) ? beam->completed : nullptr, beam->beam);
+        // samples: the cache of recording r / best_of, ended flags per sequence
+        else if (samp) cross_attention(ctx, li, ctx->dq, ctx->datt, B, samp->best_of, 0, samp->skip_ended ? samp->finished : nullptr, 1);
         else cross_attention(ctx, li, ctx->dq, ctx->datt, B, 1, 0, (ctx->skip_done && ctx->can_end && !want_logits) ? fp.finished : nullptr, 1);
     }
     if (gemv) {
@@ -931,9 +940,10 @@ static void enqueue_layer(mw_ctx* ctx, int li, int B, bool want_logits, const Fi
 }
 
 // One greedy step: 8 launches per layer + final norm + logits + token bookkeeping.
-static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int max_keys, const BeamParams* beam = nullptr) {
-    for (int li = 0; li < ctx->d.dec_layers; ++li) enqueue_layer(ctx, li, B, want_logits, fp, max_keys, beam);
-    enqueue_step_tail(ctx, B, want_logits, fp, beam);
+static void enqueue_step(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, int max_keys, const BeamParams* beam = nullptr,
+                         const SampleParams* samp = nullptr) {
+    for (int li = 0; li < ctx->d.dec_layers; ++li) enqueue_layer(ctx, li, B, want_logits, fp, max_keys, beam, kLayerGemv | kLayerAttn, samp);
+    enqueue_step_tail(ctx, B, want_logits, fp, beam, samp);
 }
 
 static FinalizeParams finalize_params(mw_ctx* ctx, int n_forced) {
@@ -953,7 +963,8 @@ static FinalizeParams finalize_params(mw_ctx* ctx, int n_forced) {
 // weight codes expanded to fp16 with the row scale in the epilogue), on the GEMM kernels instead of the GEMVs.
 // Beam search (beam > 1): B recordings, each prompt once; the k/v rows go to the cache rows of the recording's
 // first beam, `src_rows` points every beam at them, and dx gets `beam` copies of each last row.
-static int run_prefill(mw_ctx* ctx, int B, int P, int beam = 1, int* src_rows = nullptr) {
+// kv_rep > 1 (samples): sequence b reads the cross-attention K/V of recording b / kv_rep.
+static int run_prefill(mw_ctx* ctx, int B, int P, int beam = 1, int* src_rows = nullptr, int kv_rep = 1) {
     const mw_model_desc& d = ctx->d;
     const int D = d.d_model, F = d.ffn_dim, H = d.n_heads, Tc = d.n_text_ctx;
     const int M = B * P;
@@ -978,7 +989,7 @@ static int run_prefill(mw_ctx* ctx, int B, int P, int beam = 1, int* src_rows = 
         {   GemmParams p = gemm(ctx->xn, D, l.cq, D); p.scale = qscale; p.scale_ncols = D; p.C = cq; p.ldc = D; launch_gemm(p, s); }
         for (int r0 = 0; r0 < M; r0 += kPrefillSlabRows) {
             const int rows = std::min(kPrefillSlabRows, M - r0);
-            cross_attention(ctx, li, cq + (size_t)r0 * D, ctx->att + (size_t)r0 * D, rows, P, r0);
+            cross_attention(ctx, li, cq + (size_t)r0 * D, ctx->att + (size_t)r0 * D, rows, P * kv_rep, r0);
         }
         {   GemmParams p = gemm(ctx->att, D, l.co, D); p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D; launch_gemm(p, s); }
         launch_layernorm(ctx->x, l.ln3.g, l.ln3.b, ctx->xn, nullptr, M, D, s);
@@ -1009,13 +1020,13 @@ static int poll_finished(mw_ctx* ctx, int n, int need, bool* all_done) {
 // Capture (or re-use) the graph of one step for this batch size / forced length / logits flag and the
 // self-attention bucket of `n_keys` = position + 1.  Returns the executable graph through `out`.
 static int ensure_graph(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, long key, int n_keys, hipGraphExec_t* out,
-                        const BeamParams* beam = nullptr) {
+                        const BeamParams* beam = nullptr, const SampleParams* samp = nullptr) {
     const int b = dec_self_attn_bucket(n_keys);
     if (!(ctx->graph_exec[b] && ctx->graph_batch[b] == key && ctx->graph_logits[b] == (int)want_logits)) {
         if (ctx->graph_exec[b]) { (void)hipGraphExecDestroy(ctx->graph_exec[b]); ctx->graph_exec[b] = nullptr; }
         if (ctx->graph[b]) { (void)hipGraphDestroy(ctx->graph[b]); ctx->graph[b] = nullptr; }
         HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        enqueue_step(ctx, B, want_logits, fp, n_keys, beam);
+        enqueue_step(ctx, B, want_logits, fp, n_keys, beam, samp);
         HIPCHK(hipStreamEndCapture(ctx->stream, &ctx->graph[b]));
         HIPCHK(hipGraphInstantiate(&ctx->graph_exec[b], ctx->graph[b], nullptr, nullptr, 0));
         ctx->graph_batch[b] = key; ctx->graph_logits[b] = (int)want_logits;
@@ -1025,13 +1036,20 @@ static int ensure_graph(mw_ctx* ctx, int B, bool want_logits, const FinalizePara
 }
 
 // Shared driver: feed `n_forced` given ids per sequence, then sample `max_new` more.
-static int run_decode(mw_ctx* ctx, int B, int n_forced, int max_new, float* logits_out, bool logits_every_step) {
+// `sc` (sampling at a temperature): the token bookkeeping of every step is the sampling launches', which read the
+// step's full logits.
+struct SampleCall { const SampleParams* p; float inv_temp; uint32_t seed; int n_ended_at_start; };
+static int run_decode(mw_ctx* ctx, int B, int n_forced, int max_new, float* logits_out, bool logits_every_step, const SampleCall* sc = nullptr) {
     const mw_model_desc& d = ctx->d;
     hipStream_t s = ctx->stream;
     FinalizeParams fp = finalize_params(ctx, n_forced);
-    launch_dec_init(fp, B, n_forced, max_new, ctx->eot, s);
+    const SampleParams* samp = sc ? sc->p : nullptr;
+    if (samp) launch_sample_init(*samp, n_forced, max_new, ctx->eot, sc->inv_temp, sc->seed, sc->n_ended_at_start, s);
+    else launch_dec_init(fp, B, n_forced, max_new, ctx->eot, s);
     HIPCHK(hipGetLastError());
-    const bool want_logits = logits_out != nullptr;
+    const bool copy_logits = logits_out != nullptr;
+    const bool want_logits = copy_logits || samp != nullptr;
+    const long graph_key = (samp ? ((1L << 48) | ((long)samp->best_of << 40) | ((long)samp->skip_ended << 39)) : 0L) | ((long)B * 1024 + n_forced);
     const int n_steps = max_new > 0 ? n_forced + max_new - 1 : n_forced;
     const bool graph = ctx->use_graph != 0;
     const size_t row = (size_t)B * d.vocab;
@@ -1040,23 +1058,23 @@ static int run_decode(mw_ctx* ctx, int B, int n_forced, int max_new, float* logi
     int first_step = 0;
     // kv_div == 1 means "own cache" to the cross-attention launcher, so a single-row prompt keeps stepping
     if (ctx->use_prefill && !logits_every_step && max_new > 0 && n_forced >= 2) {
-        int r = run_prefill(ctx, B, n_forced);              // positions 0 .. n_forced-1 in one pass
+        int r = run_prefill(ctx, B, n_forced, 1, nullptr, samp ? samp->best_of : 1);    // positions 0 .. n_forced-1 in one pass
         if (r) return r;
-        enqueue_step_tail(ctx, B, want_logits, fp);         // logits of the last prompt position choose the first sampled token
+        enqueue_step_tail(ctx, B, want_logits, fp, nullptr, samp);     // logits of the last prompt position choose the first sampled token
         HIPCHK(hipGetLastError());
-        if (want_logits) HIPCHK(hipMemcpyAsync(logits_out, ctx->logits, row * 4, hipMemcpyDefault, s));
+        if (copy_logits) HIPCHK(hipMemcpyAsync(logits_out, ctx->logits, row * 4, hipMemcpyDefault, s));
         first_step = n_forced;
         steps_run = n_forced;
     }
     for (int step = first_step; step < n_steps; ++step) {       // step feeds position `step`: step + 1 cached keys
         if (graph) {
             hipGraphExec_t g;
-            int r = ensure_graph(ctx, B, want_logits, fp, (long)B * 1024 + n_forced, step + 1, &g);
+            int r = ensure_graph(ctx, B, want_logits, fp, graph_key, step + 1, &g, nullptr, samp);
             if (r) return r;
             HIPCHK(hipGraphLaunch(g, s));
-        } else { enqueue_step(ctx, B, want_logits, fp, step + 1); HIPCHK(hipGetLastError()); }
+        } else { enqueue_step(ctx, B, want_logits, fp, step + 1, nullptr, samp); HIPCHK(hipGetLastError()); }
         ++steps_run;
-        if (want_logits) {
+        if (copy_logits) {
             // step feeds position `step`; its logits choose the token for position step + 1
             if (logits_every_step) {
                 HIPCHK(hipMemcpyAsync(logits_out + (size_t)step * row, ctx->logits, row * 4, hipMemcpyDefault, s));
@@ -1216,6 +1234,85 @@ extern "C" int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience
                     hyp_ids[((size_t)a * beam + c) * max_new + i] = (have && i < hyps[c].len) ? hyps[c].tok[i] : ctx->eot;
         }
     }
+    return MW_OK;
+}
+
+extern "C" float mw_sample_uniform(uint32_t seed, uint32_t sequence, uint32_t position, uint32_t token) {
+    return sample_uniform(seed, sequence, position, token);
+}
+
+// Samples at a temperature over the encoder state of the last mw_encode: n_audio recordings x best_of samples run
+// as n_audio*best_of sequences through the step kernels of greedy decoding (cross-attention reads the cache of
+// recording r / best_of, every sequence keeps its own self-attention cache), token bookkeeping in the sampling
+// launches, the choice among a recording's samples on the host.
+extern "C" int mw_decode_sample(mw_ctx* ctx, int n_audio, int best_of, float temperature, uint32_t seed, const uint8_t* active,
+                                int32_t* out_ids, int32_t* out_len, float* out_avg_logprob, int32_t* smp_ids, int32_t* smp_len,
+                                float* smp_sum_logprob, float* logits_out) {
+    if (!ctx) return MW_ERR_ARG;
+    if (!ctx->opts_set) return fail(ctx, MW_ERR_STATE, "mw_decode_sample: call mw_set_decode_opts first");
+    if (best_of < 1 || best_of > kMaxBeam) return fail(ctx, MW_ERR_ARG, "mw_decode_sample: best_of must be in 1.." + std::to_string(kMaxBeam));
+    if (!(temperature >= 0.0f) || temperature > 100.0f) return fail(ctx, MW_ERR_ARG, "mw_decode_sample: temperature must be in [0, 100]");
+    if (n_audio < 1 || n_audio * best_of > ctx->max_batch)
+        return fail(ctx, MW_ERR_ARG, "mw_decode_sample: n_audio * best_of must be in 1.." + std::to_string(ctx->max_batch) + " (max_batch)");
+    if (ctx->enc_batch != n_audio) return fail(ctx, MW_ERR_STATE, "mw_decode_sample: n_audio differs from the last mw_encode");
+    if (!out_ids || !out_len) return fail(ctx, MW_ERR_ARG, "mw_decode_sample: null output");
+    HIPCHK(hipSetDevice(ctx->device));
+    const mw_model_desc& d = ctx->d;
+    const int R = n_audio * best_of, P = (int)ctx->prompt.size(), max_new = ctx->max_new;
+    if (!ctx->ss) {                 // first use: sized for max_batch sequences
+        const size_t MB = ctx->max_batch;
+        ALLOC(ctx->ss, 1); ALLOC(ctx->sp_sum_lp, MB); ALLOC(ctx->sp_active, MB);
+        ALLOC(ctx->sp_part_m, MB * kBeamParts); ALLOC(ctx->sp_part_s, MB * kBeamParts); ALLOC(ctx->sp_part_v, MB * kBeamParts);
+        ALLOC(ctx->sp_part_l, MB * kBeamParts); ALLOC(ctx->sp_part_i, MB * kBeamParts);
+    }
+    int n_ended = 0;
+    if (active) {
+        for (int a = 0; a < n_audio; ++a) n_ended += active[a] ? 0 : best_of;
+        HIPCHK(hipMemcpyAsync(ctx->sp_active, active, n_audio, hipMemcpyHostToDevice, ctx->stream));
+    }
+    std::vector<int32_t> f((size_t)R * P);
+    for (int r = 0; r < R; ++r) memcpy(&f[(size_t)r * P], ctx->prompt.data(), P * 4);
+    HIPCHK(hipMemcpyAsync(ctx->forced, f.data(), f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+
+    SampleParams sp{};
+    sp.st = ctx->st; sp.ss = ctx->ss; sp.n_audio = n_audio; sp.best_of = best_of;
+    sp.logits = ctx->logits; sp.mask_first = ctx->mask_first; sp.mask_rest = ctx->mask_rest;
+    sp.forced = ctx->forced; sp.n_forced = P;
+    sp.tok_emb = ctx->tok_emb; sp.pos_emb = ctx->dec_pos; sp.D = d.d_model; sp.n_text_ctx = d.n_text_ctx; sp.vocab = d.vocab;
+    sp.x = ctx->dx; sp.sum_lp = ctx->sp_sum_lp; sp.out_ids = ctx->out_ids; sp.out_len = ctx->out_len; sp.finished = ctx->finished;
+    sp.active = active ? ctx->sp_active : nullptr;
+    // ended sequences cost no cross-attention reads (recordings switched off from the start included), unless the
+    // caller wants the logits of every position
+    sp.skip_ended = (ctx->skip_done && (ctx->can_end || n_ended > 0) && !logits_out) ? 1 : 0;
+    sp.part_m = ctx->sp_part_m; sp.part_s = ctx->sp_part_s; sp.part_v = ctx->sp_part_v; sp.part_l = ctx->sp_part_l; sp.part_i = ctx->sp_part_i;
+    SampleCall sc{&sp, temperature > 0.0f ? 1.0f / temperature : 0.0f, seed, n_ended};
+    int r = run_decode(ctx, R, P, max_new, logits_out, false, &sc);
+    if (r) return r;
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipEventRecord(ctx->ev[4], s));
+    std::vector<int32_t> ids((size_t)R * max_new), len(R);
+    std::vector<float> lp(R);
+    HIPCHK(hipMemcpyAsync(ids.data(), ctx->out_ids, ids.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(len.data(), ctx->out_len, len.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(lp.data(), ctx->sp_sum_lp, lp.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipEventElapsedTime(&ctx->stage_ms[3], ctx->ev[3], ctx->ev[4]));
+    // per recording: the sample with the highest log-probability per token (ties: the first)
+    for (int a = 0; a < n_audio; ++a) {
+        int best = a * best_of;
+        for (int j = 1; j < best_of; ++j) {
+            const int c = a * best_of + j;
+            if (lp[c] / std::max(len[c], 1) > lp[best] / std::max(len[best], 1)) best = c;
+        }
+        memcpy(out_ids + (size_t)a * max_new, &ids[(size_t)best * max_new], (size_t)max_new * 4);
+        out_len[a] = len[best];
+        if (out_avg_logprob) out_avg_logprob[a] = lp[best] / (len[best] + 1);
+    }
+    if (smp_ids) memcpy(smp_ids, ids.data(), ids.size() * 4);
+    if (smp_len) memcpy(smp_len, len.data(), len.size() * 4);
+    if (smp_sum_logprob) memcpy(smp_sum_logprob, lp.data(), lp.size() * 4);
     return MW_OK;
 }
 

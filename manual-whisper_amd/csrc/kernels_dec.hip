@@ -1338,6 +1338,130 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
         }
 }
 
+// ------------------------------------------------------------------ sampling at a temperature
+// The decodes that OpenAI Whisper's decode_with_fallback (transcribe.py of the openai-whisper package, mirrored by
+// faster-whisper's generate_with_fallback; the reference leaves them to whisperx, transcribe.py:111) runs when a
+// window's text fails its compression-ratio or log-probability test: `best_of` independent samples per recording
+// from softmax(logits / temperature) under the suppress mask (GreedyDecoder.update of decoding.py), each summing
+// the log-probabilities (log-softmax of the untempered logits) of its sampled tokens up to and including
+// end-of-text.  The draw is a Gumbel arg-max, token = argmax_i(logits_i / temperature - log(-log u_i)) with u_i a
+// counter-based uniform of (seed, sequence, position, i): distributed as the categorical draw of the published code,
+// independent of how the vocabulary is split over workgroups, and reproducible on the host.  inv_temp == 0 is the
+// arg-max itself (temperature 0 with its log-probabilities).
+__global__ __launch_bounds__(256) void sample_init_kernel(SampleParams p, int prompt_len, int max_new, int eot, float inv_temp, uint32_t seed,
+                                                          int n_ended_at_start) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int tok = p.forced[(long)r * p.n_forced];
+    for (int c = tid; c < p.D; c += 256) p.x[(long)r * p.D + c] = (float)p.tok_emb[(long)tok * p.D + c] + (float)p.pos_emb[c];
+    for (int i = tid; i < max_new; i += 256) p.out_ids[(long)r * max_new + i] = eot;
+    if (tid == 0) {
+        const bool on = !p.active || p.active[r / p.best_of];
+        p.out_len[r] = on ? max_new : 0;
+        p.finished[r] = on ? 0 : 1;
+        p.sum_lp[r] = 0.f;
+    }
+    if (r == 0 && tid == 0) {
+        p.st->pos = 0; p.st->prompt_len = prompt_len; p.st->max_new = max_new; p.st->eot = eot;
+        p.st->n_finished = n_ended_at_start; p.st->batch = p.n_audio * p.best_of;
+        p.ss->inv_temp = inv_temp; p.ss->seed = seed;
+    }
+}
+
+// Workgroup (part, sequence): its sixteenth of the sequence's logits under the suppress mask -> running maximum and
+// sum of exp(v - maximum), and the best perturbed score with the raw logit and id behind it (ties: lowest id).
+__global__ __launch_bounds__(256) void sample_scan_kernel(SampleParams p) {
+    __shared__ float redm[4], reds[4], wv[4], wl[4];
+    __shared__ int wi[4];
+    const int part = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int next = p.st->pos, prompt_len = p.st->prompt_len;
+    if (next < prompt_len || p.finished[r]) return;
+    const uint8_t* mask = next == prompt_len ? p.mask_first : p.mask_rest;
+    const float inv_temp = p.ss->inv_temp;
+    const uint32_t seed = p.ss->seed, sample = (uint32_t)(next - prompt_len);
+    const int per = (p.vocab + kBeamParts - 1) / kBeamParts;
+    const int lo = part * per, hi = min(p.vocab, lo + per);
+    const float* lg = p.logits + (long)r * p.vocab;
+    float m = -INFINITY, ssum = 0.f, best = -INFINITY, braw = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int i = lo + tid; i < hi; i += 256) {
+        if (mask[i]) continue;
+        const float v = lg[i];
+        if (v > m) { ssum = ssum * expf(m - v) + 1.f; m = v; } else { ssum += expf(v - m); }
+        float sc = v;
+        if (inv_temp > 0.f) sc = v * inv_temp - logf(-logf(sample_uniform(seed, (uint32_t)r, sample, (uint32_t)i)));
+        if (sc > best) { best = sc; braw = v; bidx = i; }          // ids arrive in increasing order: ties keep the lower one
+    }
+    float bm = wave_max(m);
+    if (lane == 0) redm[wave] = bm;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o), ol = __shfl_xor(braw, o);
+        const int oi = __shfl_xor(bidx, o);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; braw = ol; bidx = oi; }
+    }
+    if (lane == 0) { wv[wave] = best; wl[wave] = braw; wi[wave] = bidx; }
+    __syncthreads();
+    bm = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    const float bs = wave_sum(m == -INFINITY ? 0.f : ssum * expf(m - bm));
+    if (lane == 0) reds[wave] = bs;
+    __syncthreads();
+    if (tid == 0) {
+        float gv = wv[0], gl = wl[0]; int gi = wi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (wv[w] > gv || (wv[w] == gv && wi[w] < gi)) { gv = wv[w]; gl = wl[w]; gi = wi[w]; }
+        const long slot = (long)r * kBeamParts + part;
+        p.part_m[slot] = bm; p.part_s[slot] = reds[0] + reds[1] + reds[2] + reds[3];
+        p.part_v[slot] = gv; p.part_l[slot] = gl; p.part_i[slot] = gi;
+    }
+}
+
+// One workgroup per sequence, in place of dec_finalize: merge the parts in index order, record the token and its
+// log-probability, apply the end-of-text rule, embed the next input.
+__global__ __launch_bounds__(256) void sample_step_kernel(SampleParams p) {
+    __shared__ int s_tok;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int next = p.st->pos, prompt_len = p.st->prompt_len, max_new = p.st->max_new, eot = p.st->eot;
+    if (tid == 0) {
+        int tok;
+        if (next < prompt_len) {
+            tok = p.forced[(long)r * p.n_forced + next];
+        } else if (p.finished[r]) {
+            tok = eot;
+        } else {
+            const long row = (long)r * kBeamParts;
+            float bm = -INFINITY;
+            for (int q = 0; q < kBeamParts; ++q) bm = fmaxf(bm, p.part_m[row + q]);
+            float bs = 0.f, gv = -INFINITY, gl = 0.f;
+            int gi = 0x7fffffff;
+            for (int q = 0; q < kBeamParts; ++q) {
+                const float mq = p.part_m[row + q];
+                if (mq != -INFINITY) bs += p.part_s[row + q] * expf(mq - bm);
+                const float v = p.part_v[row + q]; const int ix = p.part_i[row + q];
+                if (v > gv || (v == gv && ix < gi)) { gv = v; gl = p.part_l[row + q]; gi = ix; }
+            }
+            const bool ok = gi >= 0 && gi < p.vocab;            // false: everything masked or NaN
+            tok = ok ? gi : eot;
+            const int sample = next - prompt_len;
+            if (sample < max_new) {
+                p.out_ids[(long)r * max_new + sample] = tok;
+                if (ok) p.sum_lp[r] += gl - (bm + logf(bs));
+                if (tok == eot) {
+                    p.out_len[r] = sample;
+                    p.finished[r] = 1;
+                    atomicAdd(&p.st->n_finished, 1);
+                }
+            }
+        }
+        s_tok = tok;
+    }
+    __syncthreads();
+    const int tok = s_tok;
+    if (next < p.n_text_ctx)
+        for (int c = tid; c < p.D; c += 256)
+            p.x[(long)r * p.D + c] = (float)p.tok_emb[(long)tok * p.D + c] + (float)p.pos_emb[(long)next * p.D + c];
+}
+
 // ------------------------------------------------------------------ prompt prefill
 // The forced prompt (start-of-previous + initial prompt + task tokens: several dozen ids with the
 // reference's initial_prompt, transcribe.py:40,111) is known before decoding starts, so all of its
@@ -1789,6 +1913,17 @@ void launch_beam_step(const BeamParams& p, hipStream_t s) {
     hipLaunchKernelGGL(beam_scan_kernel, dim3(kBeamParts, p.n_audio * p.beam), dim3(256), 0, s, p);
     const size_t lds = (size_t)p.beam * p.n_text_ctx * sizeof(int);      // n_text_ctx >= max_new
     hipLaunchKernelGGL(beam_step_kernel, dim3(p.n_audio), dim3(256), lds, s, p);
+}
+
+void launch_sample_init(const SampleParams& p, int prompt_len, int max_new, int eot, float inv_temp, uint32_t seed, int n_ended_at_start,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(sample_init_kernel, dim3(p.n_audio * p.best_of), dim3(256), 0, s, p, prompt_len, max_new, eot, inv_temp, seed,
+                       n_ended_at_start);
+}
+
+void launch_sample_step(const SampleParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(sample_scan_kernel, dim3(kBeamParts, p.n_audio * p.best_of), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(sample_step_kernel, dim3(p.n_audio * p.best_of), dim3(256), 0, s, p);
 }
 
 }  // namespace mw

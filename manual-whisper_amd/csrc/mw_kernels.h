@@ -219,6 +219,47 @@ void launch_beam_init(const BeamParams& p, int prompt_len, int max_new, int eot,
 void launch_beam_step(const BeamParams& p, hipStream_t s);
 void launch_dec_finalize(const FinalizeParams& p, int B, hipStream_t s);
 
+// ---------------------------------------------------------------- sampling at a temperature (the fallback decodes)
+// Set per call by the init launch and read by the step launches (captured steps must not carry them as arguments).
+struct SampleState {
+    float inv_temp;         // 1 / temperature; 0 = arg-max (temperature 0)
+    uint32_t seed;
+    int pad[2];
+};
+// best_of independent samples per recording: sequence r reads the cross K/V of recording r / best_of and keeps a
+// self-attention cache of its own.
+struct SampleParams {
+    DecState* st; SampleState* ss;
+    int n_audio, best_of;
+    const float* logits;                    // [n_audio*best_of][vocab] of this step
+    const uint8_t* mask_first; const uint8_t* mask_rest;
+    const int* forced; int n_forced;        // [n_audio*best_of][n_forced]
+    const f16* tok_emb; const f16* pos_emb; int D; int n_text_ctx; int vocab;
+    float* x;                               // [n_audio*best_of][D] next input embeddings
+    float* sum_lp;                          // [n_audio*best_of] sum of log-probabilities of the sampled tokens (end-of-text included)
+    int* out_ids; int* out_len; int* finished;      // [n_audio*best_of][max_new], [n_audio*best_of], [n_audio*best_of]
+    const uint8_t* active;                  // [n_audio] or null: recordings with 0 start ended (length 0, nothing sampled)
+    int skip_ended;                         // 1: the cross-attention launches skip sequences whose `finished` flag is set
+    // per (sequence, vocabulary part) of this step, written by the scan launch and merged by the step launch:
+    float* part_m; float* part_s;           // running maximum and sum of exp(v - maximum) over the unmasked logits
+    float* part_v; float* part_l; int* part_i;      // best perturbed score, the raw logit behind it, its id
+};
+// Uniform in (0, 1) for (seed, sequence, sampled position, token id): three rounds of the 32-bit murmur3 finaliser;
+// the top 23 bits plus one half, so that the value is exact in float32 on every implementation.
+__host__ __device__ inline uint32_t sample_mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ inline float sample_uniform(uint32_t seed, uint32_t seq, uint32_t pos, uint32_t tok) {
+    uint32_t h = sample_mix32(seed ^ (seq * 0x9E3779B1u));
+    h = sample_mix32(h ^ (pos * 0x85EBCA77u));
+    h = sample_mix32(h ^ (tok * 0xC2B2AE3Du));
+    return ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);
+}
+void launch_sample_init(const SampleParams& p, int prompt_len, int max_new, int eot, float inv_temp, uint32_t seed, int n_ended_at_start,
+                        hipStream_t s);
+void launch_sample_step(const SampleParams& p, hipStream_t s);
+
 // ---------------------------------------------------------------- wav2vec2 front end (forced alignment)
 // First convolution of the feature extractor on the raw waveform, with its LayerNorm over channels and GELU:
 // x float32 [n] -> out fp16 [T0][C], T0 = (n - K0) / S0 + 1.  w [C][K0], b, g, beta [C] float32.  C % 64 == 0, C <= 512, K0 <= 16.

@@ -222,6 +222,35 @@ class Engine:
                                              _ptr(hs) if want_hypotheses else None), "mw_decode_beam")
         return (ids, lens, avg, hi, hl, hs) if want_hypotheses else (ids, lens, avg)
 
+    def decode_sample(self, n_audio: int, temperature: float, best_of: int = 1, seed: int = 0, active=None,
+                      want_samples: bool = False, want_logits: bool = False):
+        """``best_of`` samples per recording at ``temperature`` over the last ``encode(n_audio)`` (0 = the arg-max with its
+        log-probabilities): -> (ids [n_audio, max_new], lens, avg_logprob) of each recording's best sample; with
+        ``want_samples`` also (smp_ids [n_audio, best_of, max_new], smp_len, smp_sum_logprob); with ``want_logits`` also
+        the logits [max_new, n_audio * best_of, vocab].  ``active`` (bool [n_audio]): recordings to decode, the others
+        come back empty."""
+        if self.opts is None:
+            raise EngineError("set_decode_options first")
+        ids = np.empty((n_audio, self.opts.max_new), np.int32)
+        lens = np.empty(n_audio, np.int32)
+        avg = np.empty(n_audio, np.float32)
+        act = None if active is None else np.ascontiguousarray(np.asarray(active).astype(bool), dtype=np.uint8)
+        if act is not None and act.shape != (n_audio,):
+            raise EngineError(f"active must have shape ({n_audio},)")
+        si = np.empty((n_audio, best_of, self.opts.max_new), np.int32) if want_samples else None
+        sl = np.empty((n_audio, best_of), np.int32) if want_samples else None
+        ss = np.empty((n_audio, best_of), np.float32) if want_samples else None
+        lg = np.zeros((self.opts.max_new, n_audio * best_of, self.dims.vocab), np.float32) if want_logits else None
+        opt = lambda a: _ptr(a) if a is not None else None     # noqa: E731
+        self._check(self._lib.mw_decode_sample(self._h, n_audio, best_of, C.c_float(temperature), C.c_uint32(seed & 0xFFFFFFFF), opt(act),
+                                               _ptr(ids), _ptr(lens), _ptr(avg), opt(si), opt(sl), opt(ss), opt(lg)), "mw_decode_sample")
+        out = (ids, lens, avg)
+        if want_samples:
+            out += (si, sl, ss)
+        if want_logits:
+            out += (lg,)
+        return out
+
     def transcribe_batch_beam(self, pcm, beam: int, patience: float = 1.0):
         """log-mel -> encoder -> beam search for up to max_batch // beam chunks: -> (ids, lens), as transcribe_batch."""
         n = self._pcm_batch(pcm)

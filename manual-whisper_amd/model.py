@@ -16,8 +16,9 @@ Differences that cannot be avoided offline, all stated where they bite:
   * ``compute_type``: ``"float16"`` or ``"float8"`` (the reference's CPU default ``"int8"`` is a CTranslate2 format
     with no counterpart here).
   * decoding is greedy by default (what the throughput figures are quoted on); ``asr_options={"beam_size": 5}``
-    switches to beam search at temperature 0 (whisperx's default beam; no temperature fallback), which runs
-    ``max_batch // beam_size`` chunks per pass.  No timestamps; text needs tokenizer.json, otherwise a segment's text is
+    switches to beam search at temperature 0 (whisperx's default beam), which runs ``max_batch // beam_size`` chunks
+    per pass; ``asr_options={"temperatures": [0.0, 0.2, ...], "best_of": 5, "compression_ratio_threshold": 2.4,
+    "log_prob_threshold": -1.0}`` with more than one temperature turns on the temperature fallback (fallback.py).  No timestamps; text needs tokenizer.json, otherwise a segment's text is
     its token ids written as ``<|id|>``; ``transcribe(..., return_tokens=True)`` also returns the ids under ``"tokens"``.
 """
 from __future__ import annotations
@@ -65,7 +66,8 @@ class Model:
     def __init__(self, engine: Engine, dims: WhisperDims, language: str, tokenizer=None,
                  initial_prompt: Optional[str] = None, vad_options: Optional[dict] = None,
                  synthetic: bool = False, max_new: int = 224, n_engines: int = 1, beam_size: int = 1, patience: float = 1.0,
-                 coalesce: int = 1, arrangement: str = "coalesced", group: int = 7, n_encoders: int = 2, n_decoders: int = 3):
+                 coalesce: int = 1, arrangement: str = "coalesced", group: int = 7, n_encoders: int = 2, n_decoders: int = 3,
+                 fallback=None):
         self.engine, self.dims, self.language = engine, dims, language
         self.tokenizer, self.initial_prompt = tokenizer, initial_prompt
         self.vad_options = dict(vad_options or {})
@@ -75,11 +77,16 @@ class Model:
         if arrangement not in ("grouped", "coalesced"):
             raise EngineError(f"arrangement={arrangement!r}: 'grouped' or 'coalesced'")
         self.beam_size, self.patience = int(beam_size), float(patience)
+        # fallback.FallbackOptions naming more than one temperature: windows whose text fails the compression-ratio or
+        # log-probability test are decoded again, warmer (fallback.py); like beam search this runs whole passes per engine
+        self.fallback = fallback if (fallback is not None and fallback.enabled) else None
+        if self.fallback is not None and self.fallback.rows_per_window() > engine.max_batch:
+            raise EngineError(f"best_of / beam_size = {self.fallback.rows_per_window()} does not fit max_batch={engine.max_batch}")
         # "grouped" (greedy decoding only): encoder passes of `batch_size` chunks on `n_encoders` engines, the greedy
         # loop over up to `group` such batches at once on `n_decoders` engines (scheduler.GroupedPool), sized to the job
         # at the first call.  "coalesced" (and beam search): `n_engines` engines that each run whole passes of up to
         # `coalesce` batches (scheduler.EnginePool).
-        self.grouped = arrangement == "grouped" and self.beam_size == 1
+        self.grouped = arrangement == "grouped" and self.beam_size == 1 and self.fallback is None
         self.group, self.n_encoders, self.n_decoders = max(1, int(group)), max(1, int(n_encoders)), max(1, int(n_decoders))
         self.max_group_sequences = 128
         self.coalesce = max(1, int(coalesce))
@@ -93,7 +100,7 @@ class Model:
         only when a call needs more than the pool at hand (more chunks per batch, larger groups, more engines)."""
         if not self.grouped:
             if self.pool is None:
-                self.pool = EnginePool(self.engine, self.n_engines, self.beam_size, self.patience)
+                self.pool = EnginePool(self.engine, self.n_engines, self.beam_size, self.patience, self.fallback, self.detokenize)
                 self._pool_key = ("coalesced",)
             return self.pool
         n_batches = max(1, -(-n_chunks // batch_size))
@@ -186,7 +193,8 @@ class Model:
         if self.grouped:
             bs = max(1, min(int(batch_size), self.max_group_sequences))
         else:
-            bs = max(1, min(int(batch_size) * self.coalesce, self.engine.max_batch // self.beam_size))
+            rows = self.fallback.rows_per_window() if self.fallback is not None else self.beam_size
+            bs = max(1, min(int(batch_size) * self.coalesce, self.engine.max_batch // rows))
         pool = self._pool_for(n, bs)
         if self._opts_for != language:
             pool.set_decode_options(self.decode_options(language))
@@ -240,8 +248,10 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
     """
     coalesce = max(1, int(coalesce))
     beam = int((asr_options or {}).get("beam_size", 1))
+    from .fallback import FallbackOptions
+    fallback = FallbackOptions.from_asr_options(asr_options or {})
     if max_batch is None:
-        max_batch = 16 if (arrangement == "grouped" and beam == 1) else min(128, 16 * coalesce)
+        max_batch = 16 if (arrangement == "grouped" and beam == 1 and not fallback.enabled) else min(128, 16 * coalesce)
     if device not in _GPU_NAMES:
         raise EngineError(f"device={device!r}: this engine runs on an MI355X GPU only (use 'cuda'); there is no CPU path")
     if compute_type not in _FP16_NAMES + _FP8_NAMES:
@@ -285,4 +295,4 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
     return Model(engine, dims, language or "zh", tokenizer, asr_options.get("initial_prompt"), vad_options,
                  synthetic=synthetic, max_new=int(asr_options.get("max_new_tokens", 224)), n_engines=n_engines,
                  beam_size=int(asr_options.get("beam_size", 1)), patience=float(asr_options.get("patience", 1.0)), coalesce=coalesce,
-                 arrangement=arrangement, group=group, n_encoders=n_encoders, n_decoders=n_decoders)
+                 arrangement=arrangement, group=group, n_encoders=n_encoders, n_decoders=n_decoders, fallback=fallback)

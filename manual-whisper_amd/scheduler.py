@@ -43,10 +43,16 @@ class EnginePool:
     the chip idle; a second and third engine (own stream and caches, shared weights) fill those gaps.
     """
 
-    def __init__(self, engine, n_engines: int = 1, beam_size: int = 1, patience: float = 1.0):
+    def __init__(self, engine, n_engines: int = 1, beam_size: int = 1, patience: float = 1.0, fallback=None, detokenize=None):
         if n_engines < 1:
             raise ValueError("n_engines must be >= 1")
         self.beam_size, self.patience = int(beam_size), float(patience)
+        # fallback.FallbackOptions with more than one temperature: every pass walks the temperatures for the windows
+        # whose text fails the tests (needs `detokenize`: ids -> text)
+        self.fallback = fallback if (fallback is not None and fallback.enabled) else None
+        self.detokenize = detokenize
+        if self.fallback is not None and detokenize is None:
+            raise ValueError("temperature fallback needs detokenize")
         self.engines = [engine] + [engine.fork() for _ in range(n_engines - 1)]
         self._free: "queue.Queue" = queue.Queue()
         for e in self.engines:
@@ -60,6 +66,9 @@ class EnginePool:
     def _run(self, pcm):
         eng = self._free.get()
         try:
+            if self.fallback is not None:
+                from . import fallback as fb
+                return fb.transcribe_batch(eng, pcm, self.detokenize, self.fallback)[:2]
             if self.beam_size > 1:
                 return eng.transcribe_batch_beam(pcm, self.beam_size, self.patience)
             return eng.transcribe_batch(pcm)

@@ -196,6 +196,53 @@ def _merge_heads(x):
     return x.transpose(0, 2, 1, 3).reshape(B, T, h * hd)
 
 
+# ----------------------------------------------------------------------------
+# sampling at a temperature
+# ----------------------------------------------------------------------------
+def _mix32(h):
+    """murmur3's 32-bit finaliser on uint64 arrays holding 32-bit values."""
+    m = np.uint64(0xFFFFFFFF)
+    h = h ^ (h >> np.uint64(16))
+    h = (h * np.uint64(0x85EBCA6B)) & m
+    h = h ^ (h >> np.uint64(13))
+    h = (h * np.uint64(0xC2B2AE35)) & m
+    return h ^ (h >> np.uint64(16))
+
+
+def sample_uniform(seed: int, seq, pos: int, tok) -> np.ndarray:
+    """Counter-based uniform in (0, 1) of (seed, sequence, sampled position, token id), float32-exact:
+    three rounds of the finaliser over the keys, the top 23 bits plus one half, over 2^23."""
+    m = np.uint64(0xFFFFFFFF)
+    seq = np.asarray(seq, np.uint64)
+    tok = np.asarray(tok, np.uint64)
+    h = _mix32((np.uint64(seed & 0xFFFFFFFF) ^ ((seq * np.uint64(0x9E3779B1)) & m)) & m)
+    h = _mix32(h ^ np.uint64((pos * 0x85EBCA77) & 0xFFFFFFFF))
+    h = _mix32(h ^ ((tok * np.uint64(0xC2B2AE3D)) & m))
+    return ((h >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+
+
+def gumbel_noise(seed: int, n_seq: int, pos: int, vocab: int) -> np.ndarray:
+    """-log(-log u) for every (sequence, token id) of one sampled position, float32 [n_seq, vocab]."""
+    u = sample_uniform(seed, np.arange(n_seq)[:, None], pos, np.arange(vocab)[None, :])
+    return -np.log(-np.log(u, dtype=np.float32), dtype=np.float32)
+
+
+def sample_from_logits(logits, masked, temperature: float, seed: int, pos: int):
+    """One draw per row of ``logits`` [R, vocab] at sampled position ``pos`` under the boolean suppress mask:
+    -> (token ids [R], log-softmax(logits)[token] float64 [R], gap between the two best perturbed scores [R]).
+    Temperature 0 is the arg-max; ties resolve to the lowest id."""
+    lg = np.where(masked[None, :], -np.inf, np.asarray(logits, np.float32))
+    score = lg
+    if temperature > 0:
+        score = (lg * np.float32(1.0 / temperature) + gumbel_noise(seed, lg.shape[0], pos, lg.shape[1])).astype(np.float32)
+    tok = score.argmax(axis=1)
+    top2 = np.partition(score, -2, axis=1)[:, -2:]
+    l64 = lg.astype(np.float64)
+    mx = l64.max(axis=1)
+    lse = mx + np.log(np.exp(l64 - mx[:, None]).sum(axis=1))
+    return tok, l64[np.arange(lg.shape[0]), tok] - lse, (top2[:, 1] - top2[:, 0]).astype(np.float32)
+
+
 class WhisperOracle:
     """fp32 Whisper forward with Hugging Face state-dict names.
 
@@ -459,6 +506,64 @@ class WhisperOracle:
             lens[b] = len(toks)
             avg[b] = lp / (len(toks) + 1)
         return ids, lens, avg, hyps
+
+    # -- sampling at a temperature ------------------------------------------------
+    def sample(self, enc, prompt, max_new, eot, temperature, best_of=1, seed=0, suppress=(), begin_suppress=(), active=None):
+        """``best_of`` samples per recording at ``temperature``: the decodes of the temperature fallback.
+
+        Restates GreedyDecoder.update / MaximumLikelihoodRanker of OpenAI Whisper's decoding.py (the decoding code is
+        not in the reference tree, which leaves it to whisperx: transcribe.py:111; parity with the reference is
+        unpinned): the next token is drawn from softmax(logits / temperature) under the suppress rules (arg-max at
+        temperature 0), a sequence's score is the sum of log-softmax(logits) of its sampled tokens, end-of-text
+        included, and a recording's result is the sample with the highest score per token.  The categorical draw is
+        taken as a Gumbel arg-max over ``gumbel_noise`` so that an implementation that splits the vocabulary can
+        reproduce it (the published code draws with torch's generator, which no other implementation can).
+
+        Returns (ids int32 [B, max_new], lens, avg_logprob f32 [B], (smp_ids [B, best_of, max_new], smp_len,
+        smp_sum_lp)); ``self.last_sample_margins`` [B * best_of, max_new] holds the gap between the best and the second
+        best perturbed score of every draw.
+        """
+        enc = np.asarray(enc, dtype=np.float32)
+        B = enc.shape[0]
+        n = int(best_of)
+        R = B * n
+        rep = np.repeat(np.arange(B), n)
+        cross = [(k[rep], v[rep]) for k, v in self.cross_kv(enc)]
+        cache = [None] * self.d.dec_layers
+        sup = np.zeros(self.d.vocab, dtype=bool)
+        sup[list(suppress)] = True
+        bsup = sup.copy()
+        bsup[list(begin_suppress)] = True
+        for pos, t in enumerate(prompt):
+            logits = self.decoder_step(np.full(R, t, dtype=np.int64), pos, cache, cross)
+        pos = len(prompt)
+        ids = np.full((R, max_new), eot, np.int32)
+        lens = np.full(R, -1, np.int32)
+        if active is not None:
+            lens[~np.asarray(active, bool)[rep]] = 0
+        sum_lp = np.zeros(R, np.float64)
+        self.last_sample_margins = np.full((R, max_new), np.inf, np.float32)
+        for i in range(max_new):
+            tok, lp, margin = sample_from_logits(logits, bsup if i == 0 else sup, temperature, seed, i)
+            done = lens >= 0
+            tok = np.where(done, eot, tok)
+            ids[:, i] = tok
+            sum_lp += np.where(done, 0.0, lp)
+            self.last_sample_margins[:, i] = np.where(done, np.inf, margin)
+            lens[(~done) & (tok == eot)] = i
+            if (lens >= 0).all() or i == max_new - 1:
+                break
+            logits = self.decoder_step(tok.astype(np.int64), pos, cache, cross)
+            pos += 1
+        lens[lens < 0] = max_new
+        out_ids = np.full((B, max_new), eot, np.int32)
+        out_len = np.zeros(B, np.int32)
+        avg = np.zeros(B, np.float32)
+        for b in range(B):
+            c = [b * n + j for j in range(n)]
+            best = max(c, key=lambda r: (sum_lp[r] / max(lens[r], 1), -r))
+            out_ids[b], out_len[b], avg[b] = ids[best], lens[best], sum_lp[best] / (lens[best] + 1)
+        return out_ids, out_len, avg, (ids.reshape(B, n, max_new), lens.reshape(B, n), sum_lp.reshape(B, n).astype(np.float32))
 
     def forced_logits(self, enc, tokens):
         """Teacher-forced logits: tokens int [B, n] -> f32 [B, n, vocab]."""
