@@ -8,8 +8,8 @@ clean-up): besides rewriting text it drops filler noise, joins neighbours of one
 speech the clean-up removed.  Host code; the ids it works on come from the GPU engine unchanged.
 
 Differences from the JavaScript that cannot matter for BMP text: lengths count code points, not UTF-16 units.
-The reference's JavaScript needs a newer node than this image has, so the expected values in the tests are
-worked out by hand from the cited lines.
+Pinned by the reference's own outputs: tests/golden/segment_filter_cases.json holds what processor.js returned,
+run under node, for hand-made and random segment lists under eight environments (tools/make_filter_golden.py).
 """
 from __future__ import annotations
 

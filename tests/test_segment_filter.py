@@ -1,7 +1,7 @@
 """Segment-list post-processing of the reference's web service (web/api/lib/processor.js:52-113).
 
-The reference's JavaScript cannot run here (it needs a newer node than the image has), so every expected
-value below is worked out by hand from the cited lines: parity unpinned by execution, pinned by reading.
+The expected values of the first tests are worked out by hand from the cited lines; the last test compares with what
+the reference's JavaScript itself returned (tests/golden/segment_filter_cases.json, made by tools/make_filter_golden.py).
 """
 import copy
 import importlib
@@ -157,3 +157,38 @@ def test_options_from_environment():
     assert o.term_replacements["AAP"] == "应用" and o.term_replacements["微心"] == "微信" and o.term_replacements["a"] == "b=c"
     assert sf.FilterOptions.from_env({"TERM_REPLACEMENTS_JSON": "[1]"}).term_replacements == sf.DEFAULT_TERM_REPLACEMENTS
     assert sf.FilterOptions.from_env({}) == sf.FilterOptions()
+
+
+# ---------------------------------------------------------------------------------- the reference's own outputs
+def _same(a, b, path=""):
+    """JSON values equal; numbers to 1e-9 (both sides compute in IEEE doubles, JSON prints them shortest-round-trip)."""
+    if isinstance(a, dict) and isinstance(b, dict):
+        assert set(a) == set(b), (path, set(a) ^ set(b))
+        for k in a:
+            _same(a[k], b[k], path + "/" + str(k))
+    elif isinstance(a, list) and isinstance(b, list):
+        assert len(a) == len(b), (path, len(a), len(b))
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, path + "/" + str(i))
+    elif isinstance(a, (int, float)) and isinstance(b, (int, float)) and not isinstance(a, bool) and not isinstance(b, bool):
+        assert abs(a - b) < 1e-9, (path, a, b)
+    else:
+        assert a == b, (path, a, b)
+
+
+def test_against_outputs_of_the_reference_javascript():
+    """tests/golden/segment_filter_cases.json holds what web/api/lib/processor.js itself returned (run under node by
+    tools/make_filter_golden.py) for hand-made and random segment lists under eight environments."""
+    import json
+    import os
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "segment_filter_cases.json"), encoding="utf-8"))
+    assert len(golden["cases"]) >= 50 and len(golden["sets"]) >= 8
+    n = 0
+    for s in golden["sets"]:
+        opts = sf.FilterOptions.from_env(s["env"])
+        for case, want in zip(golden["cases"], s["outputs"]):
+            got = sf.post_process_segments(copy.deepcopy(case), opts)
+            _same(json.loads(json.dumps(got)), want["result"], f"env={s['env']} case={n % len(golden['cases'])}")
+            assert sf.format_to_markdown(got["segments"]) == want["markdown"]
+            n += 1
+    assert n == len(golden["cases"]) * len(golden["sets"])
