@@ -139,10 +139,15 @@ __global__ void bcast_rows_kernel(const float* __restrict__ table, float* __rest
 // every V^T fragment is one ds_read_b128, like the K fragments.  Output O^T has the query on the
 // lane again, so the rescale factors are per-lane scalars.
 //
-// Softmax arithmetic per score: one fma (score * log2e - max * log2e), one v_exp_f32, one add, one
-// max, half a convert.  The running max is only raised when some query of the wave exceeds it by
-// more than kRescaleGap (in log2 units), so the O / l rescale is skipped for almost every tile; P
-// then reaches at most 2^kRescaleGap, far inside fp16 range.
+// The query fragments are multiplied by log2(e) once, as they are loaded (q arrives scaled by head_dim^-0.5, a power
+// of two, from the QKV product: a factor that is not one would round differently from tile position to tile
+// position there), so the scores are exponents of 2, and the score accumulators start at minus the query's
+// reference exponent: per score the softmax costs one v_exp_f32, one add, a third of a max3 and half a convert, no
+// multiply or subtract.  The
+// reference is the first tile's maximum and is only raised when some query of the wave exceeds it by more than
+// kRescaleGap, so the O / l rescale is skipped for almost every tile; P then reaches at most 2^kRescaleGap, far
+// inside fp16 range.  (This file is compiled with -fno-honor-nans: the maxima of MFMA results then need no
+// canonicalising v_max x, x each.)
 constexpr int AQ = 128, AKV = 64;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kRescaleGap = 6.0f;
@@ -196,7 +201,11 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
         int row = q0 + qs * 16 + fr;
         if (row >= T) row = T - 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[qs][ks] = *reinterpret_cast<const half8*>(qb + (long)row * 64 + ks * 32 + fg * 8);
+        for (int ks = 0; ks < 2; ++ks) {
+            const half8 raw = *reinterpret_cast<const half8*>(qb + (long)row * 64 + ks * 32 + fg * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[qs][ks][e] = (f16)((float)raw[e] * kLog2e);     // scores become exponents of 2
+        }
     }
 
     // staging: each thread moves two 16-byte chunks of K and two of V^T per tile
@@ -229,7 +238,10 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
     float4v o[4][2];           // [head-dim tile][query tile]: O^T
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[i][0] = float4v{0, 0, 0, 0}; o[i][1] = float4v{0, 0, 0, 0}; }
-    float mrun[2] = {-1.0e30f, -1.0e30f};      // running max in log2 units (score * log2e)
+    // Reference exponent per query (log2 units).  The score
+    // accumulators START at -mrun, so the MFMAs deliver score - mrun and the exponentials take them as they come.
+    // It is set from the first tile's maxima and raised only when a later tile exceeds it by more than kRescaleGap.
+    float mrun[2] = {0.f, 0.f};
     float lrun[2] = {0.f, 0.f};
 
     const int ntile = (T + AKV - 1) / AKV;
@@ -240,11 +252,12 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
         const int buf = it & 1, kv0 = it * AKV;
         if (it + 1 < ntile) gload(kv0 + AKV);
 
-        // ---- S^T tiles: [key tile i][query tile qs]
+        // ---- S^T tiles: [key tile i][query tile qs], relative to the reference exponent
         float4v sc[4][2];
+        const float n0 = -mrun[0], n1 = -mrun[1];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            sc[i][0] = float4v{0, 0, 0, 0}; sc[i][1] = float4v{0, 0, 0, 0};
+            sc[i][0] = float4v{n0, n0, n0, n0}; sc[i][1] = float4v{n1, n1, n1, n1};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const half8 kf = *reinterpret_cast<const half8*>(&lds[buf][0][swz64(i * 16 + fr, ks * 4 + fg)]);
@@ -266,29 +279,32 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
             float m = fmaxf(fmaxf(sc[0][qs][0], sc[0][qs][1]), fmaxf(sc[0][qs][2], sc[0][qs][3]));
 #pragma unroll
             for (int i = 1; i < 4; ++i) m = fmaxf(m, fmaxf(fmaxf(sc[i][qs][0], sc[i][qs][1]), fmaxf(sc[i][qs][2], sc[i][qs][3])));
-            mx[qs] = quad_column_max(m) * kLog2e;
+            mx[qs] = quad_column_max(m);
         }
-        if (__any(mx[0] > mrun[0] + kRescaleGap || mx[1] > mrun[1] + kRescaleGap)) {     // wave-uniform, rare after the first tiles
+        if (it == 0 || __any(mx[0] > kRescaleGap || mx[1] > kRescaleGap)) {     // wave-uniform, rare after the first tile
 #pragma unroll
             for (int qs = 0; qs < 2; ++qs) {
-                const float mnew = fmaxf(mrun[qs], mx[qs]);
-                const float alpha = __builtin_amdgcn_exp2f(mrun[qs] - mnew);
-                mrun[qs] = mnew;
+                // first tile: the reference becomes its maximum (nothing accumulated yet, so nothing to rescale)
+                const float delta = it == 0 ? mx[qs] : fmaxf(mx[qs], 0.f);
+                const float alpha = it == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                mrun[qs] += delta;
                 lrun[qs] *= alpha;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { o[i][qs][0] *= alpha; o[i][qs][1] *= alpha; o[i][qs][2] *= alpha; o[i][qs][3] *= alpha; }
+                for (int i = 0; i < 4; ++i) {
+                    o[i][qs][0] *= alpha; o[i][qs][1] *= alpha; o[i][qs][2] *= alpha; o[i][qs][3] *= alpha;
+                    sc[i][qs][0] -= delta; sc[i][qs][1] -= delta; sc[i][qs][2] -= delta; sc[i][qs][3] -= delta;
+                }
             }
         }
         half8 pf[2][2];            // [query tile][k step of 32 keys]
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
-            const float nm = -mrun[qs];
             float ps = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[i][qs][r], kLog2e, nm));
+                    const float pv = __builtin_amdgcn_exp2f(sc[i][qs][r]);
                     sc[i][qs][r] = pv;
                     ps += pv;
                 }
