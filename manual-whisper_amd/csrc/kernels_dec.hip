@@ -634,14 +634,27 @@ constexpr int LCH = 8;
 template <int MT>
 __global__ __launch_bounds__(512) void logits_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (gridDim.y > 1) group_view(p, blockIdx.y, 16 * MT);
+    // More than 16*MT sequences: every 128 vocabulary rows (a "part") are multiplied once per group of 16*MT sequences.
+    // Workgroup ids are dealt to the 8 XCDs in turn and each XCD has its own L2, so the groups of one part take
+    // CONSECUTIVE ids of ONE XCD (id = (slot * n_groups + group) * 8 + xcd, part = slot * 8 + xcd): the first of
+    // them brings the part's 128 embedding rows into that L2 and the others find them there.  (With one grid row
+    // per group the groups of a part sat 406 ids apart on different XCDs, and HBM sent the 133 MB embedding once
+    // per group: 537 MB per launch at 112 sequences by the fetch counter.)
+    int part = blockIdx.x;
+    if (p.B > 16 * MT) {
+        const int n_groups = (p.B + 16 * MT - 1) / (16 * MT);
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        part = (idx / n_groups) * 8 + xcd;
+        if (part >= p.n_parts) return;                  // padding of the last slot (the whole workgroup leaves)
+        group_view(p, idx % n_groups, 16 * MT);
+    }
     f16* xs = reinterpret_cast<f16*>(smem);                                // [16*MT][K+8]
     const int ldx = p.K + 8;
     float* cand_v = reinterpret_cast<float*>(smem + (size_t)16 * MT * ldx * 2);   // [8][16*MT]
     int* cand_i = reinterpret_cast<int*>(cand_v + 8 * 16 * MT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int tile = blockIdx.x * 8 + wave;
+    const int tile = part * 8 + wave;
     const int n0 = tile * 16;
     const int wrow = min(n0 + fr, p.N - 1);
     const f16* wp = p.W + (long)wrow * p.K + fg * 8;
@@ -716,8 +729,8 @@ __global__ __launch_bounds__(512) void logits_kernel(GemvParams p) {
             const int oi = cand_i[w * 16 * MT + tid];
             if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
         }
-        p.part_val[(long)tid * p.n_parts + blockIdx.x] = best;
-        p.part_idx[(long)tid * p.n_parts + blockIdx.x] = bidx;
+        p.part_val[(long)tid * p.n_parts + part] = best;
+        p.part_idx[(long)tid * p.n_parts + part] = bidx;
     }
 }
 
@@ -1772,7 +1785,8 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
     static const int group_mt = getenv("MW_GROUP_MT") ? atoi(getenv("MW_GROUP_MT")) : 2;
     const int mt = p.B <= 16 ? 1 : p.B < group_from ? 2 : group_mt;
     if (p.out_mode == GV_LOGITS) {
-        dim3 grid(gemv_logits_parts(p.N), (p.B + 16 * mt - 1) / (16 * mt));
+        const int parts = gemv_logits_parts(p.N), n_groups = (p.B + 16 * mt - 1) / (16 * mt);
+        dim3 grid(n_groups > 1 ? (parts + 7) / 8 * 8 * n_groups : parts);      // several groups: see the id mapping in logits_kernel
         const size_t lds = (size_t)16 * mt * (p.K + 8) * 2 + (size_t)8 * 16 * mt * 8;
         if (mt == 1) hipLaunchKernelGGL(logits_kernel<1>, grid, dim3(512), lds, s, p);
         else hipLaunchKernelGGL(logits_kernel<2>, grid, dim3(512), lds, s, p);
