@@ -513,14 +513,16 @@ __global__ __launch_bounds__(kDecGemmWaves * 64) void gemm_dec_kernel(GemvParams
     const int nk = min(nks, k0 + ks_per) - k0;          // >= 1: the launcher never creates an empty range
 
     // ---- activation slice -> LDS by LDS-DMA: slot s = row * PPS + piece; slots past the range (and the pad slot)
-    // repeat the row's last piece, rows >= B repeat the last sequence (never stored)
+    // repeat the row's last piece, rows >= B of the last tile that holds a sequence repeat the last sequence (never stored)
     {
         constexpr int NI = dec_gemm_lds_bytes<MT, KR, W8>() / 16 / (NW * 64);
         const int ppr = nk * (KSTEP / 8);
+        const int live_rows = (p.B + 15) / 16 * 16;          // tiles past the last sequence are neither filled nor published
         const f16* xbase = p.xin16 + (long)k0 * KSTEP;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int slot = (j * NW + wave) * 64 + lane;
+            if (((j * NW + wave) * 64) / PPS >= live_rows) continue;  // (wave-uniform)
             const int r = slot / PPS, c8 = slot - r * PPS;             // PPS is a compile-time constant
             const f16* src = xbase + (long)min(r, p.B - 1) * p.K + min(c8, ppr - 1) * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -558,6 +560,8 @@ __global__ __launch_bounds__(kDecGemmWaves * 64) void gemm_dec_kernel(GemvParams
         }
     }
     // lane holds out[(mg*TPW + t)*16 + fr][n .. n+3] of this K range, n = n0 + rt*16 + 4*fg
+    // sequence tiles of this wave that hold a sequence (the products of the others were taken over unfilled LDS and go nowhere)
+    const int n_live = __builtin_amdgcn_readfirstlane(min(TPW, max(0, (p.B + 15) / 16 - mg * TPW)));
     if (S > 1) {
         // slab[rg][split][wave][TPW][64 lanes] float4: every store and load 16 bytes per lane, 1 KiB contiguous per
         // wave, write-through / L1-bypassing (sc1: aux 16); narrower sc1 stores cost a fabric write each
@@ -567,6 +571,7 @@ __global__ __launch_bounds__(kDecGemmWaves * 64) void gemm_dec_kernel(GemvParams
         const int mine = (((split * NW + wave) * TPW) * 64 + lane) * 16;
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
+            if (t >= n_live) break;
             const u32x4 bits = {__float_as_uint(acc[t][0]), __float_as_uint(acc[t][1]), __float_as_uint(acc[t][2]), __float_as_uint(acc[t][3])};
             __builtin_amdgcn_raw_buffer_store_b128(bits, slab, mine + t * 1024, 0, 16);
         }
@@ -576,12 +581,20 @@ __global__ __launch_bounds__(kDecGemmWaves * 64) void gemm_dec_kernel(GemvParams
         __syncthreads();
         if (!s_last) return;
         // last arriver: all S partials of this row group are complete; every wave sums its own tiles in index order
+        // (this workgroup's own tiles are still in its registers: they take their place in the order without a read)
+        float4v own[TPW];
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = float4v{0, 0, 0, 0};
+        for (int t = 0; t < TPW; ++t) { own[t] = acc[t]; acc[t] = float4v{0, 0, 0, 0}; }
         for (int i = 0; i < S; ++i) {
+            if (i == split) {
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) acc[t] += own[t];
+                continue;
+            }
             const int theirs = (((i * NW + wave) * TPW) * 64 + lane) * 16;
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
+                if (t >= n_live) break;
                 const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(slab, theirs + t * 1024, 0, 16);
                 acc[t][0] += __uint_as_float(bits[0]); acc[t][1] += __uint_as_float(bits[1]);
                 acc[t][2] += __uint_as_float(bits[2]); acc[t][3] += __uint_as_float(bits[3]);
