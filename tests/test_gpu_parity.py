@@ -160,6 +160,20 @@ def test_batch_invariance_and_determinism(micro):
     assert (ids3 == ids16[3:6]).all()
 
 
+def test_encoder_output_bits_do_not_depend_on_the_pass(micro):
+    """A recording's encoder output is the same bits alone and as any row of a larger pass: the products round a
+    row the same way wherever it lies in a tile (q carries a power-of-two scale only; the attention's log2(e)
+    factor is applied inside its kernel)."""
+    dims, w, eng = micro
+    pcm = synth.make_pcm_np(5, seed=21)
+    mel = eng.logmel(pcm)
+    whole = eng.encode(5, mel=mel)
+    for i in (0, 1, 4):
+        alone = eng.encode(1, mel=mel[i:i + 1])
+        assert np.array_equal(alone[0], whole[i]), f"row {i} differs by {np.abs(alone[0] - whole[i]).max():.3e}"
+    assert np.array_equal(eng.encode(5, mel=mel), whole)
+
+
 def test_full_batch_matches_oracle(micro):
     dims, w, eng = micro
     opts = synthetic_options(dims, max_new=6)
