@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 
 namespace mw {
 
@@ -932,6 +933,127 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
         out[(long)bh * 64 + lane] = (f16)(O / L);
         if (lane == 0) __hip_atomic_store(tickets + bh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
+}
+
+// ------------------------------------------------------------------ cross-attention of a large decode group
+// One workgroup per (sequence, head) walks ALL the keys in chunks of 256 rows (8 per thread) with a
+// running (max, sum, output) per thread: no key ranges, no published partials, no ticket.  With thousands of
+// (sequence, head) pairs in a launch the ranges of dec_attn_kernel are not needed to fill the chip, and their
+// hand-off is what that kernel pays for them: a read stream shaped like this launch (860 MB in 8960 items of 96 KB,
+// tools/read_bw2.hip) runs at 6.85-6.9 TB/s with a barrier and an agent-scope store per item and at 6.35-6.45 TB/s
+// once every item also takes a returning agent-scope atomic (the ticket) and every fourth merges: the wave that
+// waits for its ticket holds its workgroup's slot.  Here the next chunk's K rows are requested as soon as the
+// scores have freed their registers and its V rows as soon as the outputs have, so a workgroup always has loads in
+// flight; the only barrier is the one before the final merge of the four waves.  Every thread keeps its own
+// reference maximum (the 8 lanes of a row share it), merged at the end in a fixed order: lanes by butterfly, waves
+// in index order.
+template <bool DONE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void cross_attn_stream_kernel(
+    const f16* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc, f16* __restrict__ out, int H, int T,
+    const int* __restrict__ done, int done_div) {
+    constexpr int NG = 32, RPT = 8, CH = NG * RPT, NWV = 4;
+    __shared__ float wm[NWV], wl[NWV], wo[NWV][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = DONE ? blockIdx.y * H + blockIdx.x : blockIdx.x;
+    if constexpr (DONE) {
+        if (done[blockIdx.y / done_div]) return;          // an ended sequence: its token is fixed whatever this computes
+    }
+    const int rg = tid >> 3, dc = tid & 7;
+    // workgroup-uniform bases and 32-bit element offsets (a sequence's head is T * 64 < 2^31 elements)
+    const f16* kb = kc + (long)bh * T * 64;
+    const f16* vb = vc + (long)bh * T * 64;
+    auto row_off = [&](int c, int i) -> unsigned { return (unsigned)(min(c * CH + rg + NG * i, T - 1) * 64 + dc * 8); };
+    half8 kv[RPT], vv[RPT];
+    // the query first (loads retire in order: requested last it would be waited for behind the whole first chunk),
+    // then the first chunk: all K rows, then all V rows, in the order the loop issues them
+    const half8 qh = *reinterpret_cast<const half8*>(q + (long)bh * 64 + dc * 8);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) kv[i] = load_half8<kNtXattn>(kb + row_off(0, i));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) vv[i] = load_half8<kNtXattn>(vb + row_off(0, i));
+    __builtin_amdgcn_sched_barrier(0);
+    float qv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j];
+    float m = -3.0e38f, l = 0.f;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int nch = (T + CH - 1) / CH;
+    // MORE: another chunk follows; its K rows are requested as soon as the scores have freed kv, its V rows as soon
+    // as the outputs have freed vv.  The last chunk is a copy of the body without those requests, so that the load
+    // counters the compiler waits on are exact in both (one body for both would wait for the smaller count).
+    auto chunk = [&](int c, auto more_c) {
+        constexpr bool MORE = decltype(more_c)::value;
+        // ---- scores of this chunk (rows past T are duplicates of row T-1 and are masked out)
+        float sv[RPT];
+        float cm = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += qv[j] * (float)kv[i][j];
+            d += __shfl_xor(d, 1);
+            d += __shfl_xor(d, 2);
+            d += __shfl_xor(d, 4);
+            sv[i] = (c * CH + rg + NG * i < T) ? d : -3.0e38f;
+            cm = fmaxf(cm, sv[i]);
+        }
+        if constexpr (MORE) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) kv[i] = load_half8<kNtXattn>(kb + row_off(c + 1, i));
+        }
+        // ---- running softmax of this thread's rows (a thread whose rows are all masked keeps its state: exp(-huge) = 0)
+        const float mn = fmaxf(m, cm);
+        const float alpha = __expf(m - mn);
+        l *= alpha;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= alpha;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const float pr = __expf(sv[i] - mn);
+            l += pr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += pr * (float)vv[i][j];
+        }
+        m = mn;
+        if constexpr (MORE) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) vv[i] = load_half8<kNtXattn>(vb + row_off(c + 1, i));
+        }
+    };
+    for (int c = 0; c + 1 < nch; ++c) chunk(c, std::true_type{});
+    chunk(nch - 1, std::false_type{});
+    // ---- merge the 8 row groups of a wave (lanes that share dc): butterfly over lane bits 3..5
+#pragma unroll
+    for (int o = 8; o <= 32; o <<= 1) {
+        const float m2 = __shfl_xor(m, o), l2 = __shfl_xor(l, o);
+        const float mn = fmaxf(m, m2);
+        const float a1 = __expf(m - mn), a2 = __expf(m2 - mn);
+        l = l * a1 + l2 * a2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = acc[j] * a1 + __shfl_xor(acc[j], o) * a2;
+        m = mn;
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wo[wave][lane * 8 + j] = acc[j];
+        if (lane == 0) { wm[wave] = m; wl[wave] = l; }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // ---- merge the four waves in index order; lane = output element
+    float gm = wm[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) gm = fmaxf(gm, wm[w]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+        const float a = __expf(wm[w] - gm);
+        L += a * wl[w];
+        O += a * wo[w][lane];
+    }
+    out[(long)bh * 64 + lane] = (f16)(O / L);
 }
 
 // ------------------------------------------------------------------ cross-attention over an e4m3 cache
@@ -1885,6 +2007,15 @@ void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out,
     // (two per CU: 5.80), the benchmark step 160.5 -> 159.0 ms.  Launches that fit the chip in one round keep five.
     static const int xlds_env = getenv("MW_XATTN_LDS") ? atoi(getenv("MW_XATTN_LDS")) : -1;
     const size_t xlds = xlds_env >= 0 ? (size_t)xlds_env : ((long)B * H * kXattnSplit >= 2 * 1280 ? 40000 : 0);
+    // Decode groups (at least ~4 (sequence, head) pairs per CU): one workgroup per pair walks all the keys, no key
+    // ranges and no ticket hand-off (cross_attn_stream_kernel); three workgroups per CU as above.
+    static const int stream_from = getenv("MW_XSTREAM_FROM") ? atoi(getenv("MW_XSTREAM_FROM")) : 1024;
+    static const int stream_lds = getenv("MW_XSTREAM_LDS") ? atoi(getenv("MW_XSTREAM_LDS")) : 0;    // 150 registers: three per CU as it is
+    if (kv_div == 1 && stream_from > 0 && (long)B * H >= stream_from) {
+        if (done) hipLaunchKernelGGL(cross_attn_stream_kernel<true>, dim3(H, B), dim3(256), (size_t)stream_lds, s, q, kc, vc, out, H, T, done, done_div);
+        else hipLaunchKernelGGL(cross_attn_stream_kernel<false>, dim3(B * H), dim3(256), (size_t)stream_lds, s, q, kc, vc, out, H, T, done, done_div);
+        return;
+    }
     if (kv_div > 1) {
         if (done) hipLaunchKernelGGL((dec_attn_kernel<256, 12, kXattnSplit, false, true, true>), g2, dim3(256), xlds, s, q, kc, vc, out, H, T, T,
                                      nost, partial, tickets, kv_div, norows, row0, done, done_div);

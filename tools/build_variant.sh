@@ -7,8 +7,9 @@ out=$root/tools/ab/$name
 mkdir -p $out
 cd $root/manual-whisper_amd/csrc
 pids=()
-for f in engine kernels_mel kernels_gemm kernels_enc kernels_dec kernels_vad; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function "$@" -c $f.hip -o $out/$f.o &
+for f in engine kernels_mel kernels_gemm kernels_enc kernels_dec kernels_vad kernels_w2v aligner; do
+  extra=""; [ $f = kernels_enc ] && extra="-fno-honor-nans"       # as manual_whisper_amd/build.py
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $extra "$@" -c $f.hip -o $out/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
