@@ -43,7 +43,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix (v_mfma_f32_32x32x2_f32: 2
 # (2 x FETCH_SIZE 60335.4 KB + WRITE_SIZE 530 KB, profiles/round2_pmc_counters_f16.csv); algorithmic bytes are 122.88 MB.
 XATTN_TRAFFIC_BYTES = 2 * 60335.6 * 1024 + 530.0 * 1024
 # the same at 112 sequences, the shape of a decode group (algorithmic 860.16 MB), profiles/round2_pmc_counters_f16_b112.csv
-XATTN_TRAFFIC_BYTES_112 = 2 * 421998.8 * 1024 + 3710.0 * 1024
+XATTN_TRAFFIC_BYTES_112 = 2 * 420437.0 * 1024 + 280.0 * 1024        # cross_attn_stream_kernel, grid 573440
 # the same for cross_attn8_kernel (e4m3 cache; algorithmic 65.28 MB), profiles/round1d_pmc_counters_fp8_kv8.csv
 XATTN8_TRAFFIC_BYTES = 2 * 32439.7 * 1024 + 530.0 * 1024
 BATCH = 16
@@ -424,7 +424,8 @@ def main(argv=None):
             "decode_steps_per_step": int(stage.get("decode_steps", 0)),
             "stage_roofline": stage_rooflines(dims, batch, len(opts.prompt), NEW_TOKENS, solo_ms, 1 if args.weights == "fp8" else 2, args.kv == "fp8"),
             "whole_run": None,
-            "roofline": {"kernel": ("dec_attn_kernel<256,12,4>" if args.kv == "f16" else "cross_attn8_kernel<256,12,4>")
+            "roofline": {"kernel": (("cross_attn_stream_kernel" if (grouped and batch * args.group * dims.n_heads >= 1024) else "dec_attn_kernel<256,12,4>")
+                                    if args.kv == "f16" else "cross_attn8_kernel<256,12,4>")
                                    + " (decode cross-attention, one launch per layer per token)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "sequences": ca_seqs,

@@ -59,6 +59,7 @@ struct mw_ctx {
     std::vector<void*> allocs;
     bool finalized = false;
     int use_graph = 1, check_every = 4, use_prefill = 1, skip_done = 1;
+    int xattn_stream_from = 1024;       // (sequence, head) pairs from which the decode cross-attention walks all keys per workgroup
     bool can_end = true;                    // false when the decode options suppress end-of-text everywhere
     const mw_ctx* parent = nullptr;                       // non-null: weights and tables belong to `parent`
 
@@ -389,7 +390,7 @@ extern "C" int mw_fork_sized(mw_ctx* parent, int max_batch, mw_ctx** out) {
     mw_ctx* ctx = new mw_ctx();
     ctx->d = parent->d; ctx->device = parent->device; ctx->max_batch = max_batch;
     ctx->use_graph = parent->use_graph; ctx->check_every = parent->check_every; ctx->use_prefill = parent->use_prefill;
-    ctx->skip_done = parent->skip_done;
+    ctx->skip_done = parent->skip_done; ctx->xattn_stream_from = parent->xattn_stream_from;
     ctx->parent = parent; ctx->finalized = true;
     // shared, read-only on the hot path
     ctx->conv1_w = parent->conv1_w; ctx->conv1_b = parent->conv1_b; ctx->conv2_w = parent->conv2_w; ctx->conv2_b = parent->conv2_b;
@@ -436,6 +437,10 @@ extern "C" int mw_set_option(mw_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "skip_done")) {
         if (ctx->skip_done != (value != 0)) { int r = drop_graphs(ctx); if (r) return r; }
         ctx->skip_done = value != 0;
+    }
+    else if (!strcmp(key, "xattn_stream_from")) {
+        if (ctx->xattn_stream_from != value) { int r = drop_graphs(ctx); if (r) return r; }
+        ctx->xattn_stream_from = value;
     }
     else return fail(ctx, MW_ERR_ARG, std::string("mw_set_option: unknown key ") + key);
     return MW_OK;
@@ -857,7 +862,7 @@ static void cross_attention(mw_ctx* ctx, int li, const f16* q, f16* out, int row
                                ctx->stream, kv_div, row0, done, done_div);
     } else {
         launch_dec_cross_attn(q, ctx->crossK + li * per_layer, ctx->crossV + li * per_layer, out, rows, d.n_heads, d.n_audio_ctx,
-                              ctx->xpartial, ctx->xtickets, ctx->stream, kv_div, row0, done, done_div);
+                              ctx->xpartial, ctx->xtickets, ctx->stream, kv_div, row0, done, done_div, ctx->xattn_stream_from);
     }
 }
 

@@ -1996,7 +1996,7 @@ void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, 
 }
 
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
-                           int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div) {
+                           int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div, int stream_from_arg) {
     // 4 key ranges of 375 frames per (sequence, head); 256 threads = 32 row groups x 12 rows = 384 >= 375
     const dim3 g1(B * H * kXattnSplit), g2(H * kXattnSplit, B);
     const DecState* nost = nullptr;
@@ -2009,7 +2009,8 @@ void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out,
     const size_t xlds = xlds_env >= 0 ? (size_t)xlds_env : ((long)B * H * kXattnSplit >= 2 * 1280 ? 40000 : 0);
     // Decode groups (at least ~4 (sequence, head) pairs per CU): one workgroup per pair walks all the keys, no key
     // ranges and no ticket hand-off (cross_attn_stream_kernel); three workgroups per CU as above.
-    static const int stream_from = getenv("MW_XSTREAM_FROM") ? atoi(getenv("MW_XSTREAM_FROM")) : 1024;
+    static const int stream_from_env = getenv("MW_XSTREAM_FROM") ? atoi(getenv("MW_XSTREAM_FROM")) : -1;     // A/B runs
+    const int stream_from = stream_from_env >= 0 ? stream_from_env : stream_from_arg;
     static const int stream_lds = getenv("MW_XSTREAM_LDS") ? atoi(getenv("MW_XSTREAM_LDS")) : 0;    // 150 registers: three per CU as it is
     if (kv_div == 1 && stream_from > 0 && (long)B * H >= stream_from) {
         if (done) hipLaunchKernelGGL(cross_attn_stream_kernel<true>, dim3(H, B), dim3(256), (size_t)stream_lds, s, q, kc, vc, out, H, T, done, done_div);

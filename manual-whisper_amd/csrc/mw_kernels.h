@@ -160,8 +160,11 @@ constexpr int kXattnSplit = 4;
 // recording; the prompt positions of one sequence).  row0: index of this launch's first row in the whole list.
 // done != null: rows r with done[(row0 + r) / done_div] != 0 are skipped (`out` keeps what it held): sequences
 // that have ended, recordings whose beam search is complete.
+// stream_from: from this many (sequence, head) pairs on (and kv_div == 1) one workgroup per pair walks all the keys
+// (cross_attn_stream_kernel) instead of four key ranges per pair merged through tickets; <= 0: never.
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
-                           int* tickets, hipStream_t s, int kv_div = 1, int row0 = 0, const int* done = nullptr, int done_div = 1);
+                           int* tickets, hipStream_t s, int kv_div = 1, int row0 = 0, const int* done = nullptr, int done_div = 1,
+                           int stream_from = 1024);
 // The same over an e4m3 cache: k8, v8 [B][H][T][64] codes, ks, vs [B][H][T] row scales
 void launch_dec_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
                             int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div = 1, int row0 = 0,

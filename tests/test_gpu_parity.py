@@ -82,6 +82,15 @@ def test_forced_logits_vs_oracle(setup):
     assert np.abs(got - want).max() < LOGIT_ATOL
     P = len(g["prompt"])
     np.testing.assert_allclose(got[:, :P][:, :, g["probe_cols"]], g["prompt_probe"], atol=LOGIT_ATOL, rtol=0)
+    # the cross-attention form of large decode groups (one workgroup per (sequence, head) walking all keys with a
+    # running softmax per thread), forced at this size: the same logits to the same tolerance
+    eng.set_option("xattn_stream_from", 1)
+    try:
+        walked = eng.decode_forced(toks)
+    finally:
+        eng.set_option("xattn_stream_from", 1024)
+    assert np.abs(walked - want).max() < LOGIT_ATOL
+    assert np.abs(walked - got).max() < LOGIT_ATOL
 
 
 @pytest.mark.parametrize("graph", [0, 1])
@@ -251,6 +260,16 @@ def test_ended_sequences_are_skipped_without_changing_ids(B, formats):
         ids1, lens1 = eng.transcribe_batch(pcm)
         assert (ids0 == ids1).all() and (lens0 == lens1).all()
         assert (lens1 == 0).any() and (lens1 > 0).any()            # some ended at once, some ran on
+        if formats[1] == "f16":
+            # the cross-attention form of large decode groups (one workgroup per (sequence, head) walking all keys),
+            # forced at this size, with and without the ended flags: same ids
+            eng.set_option("xattn_stream_from", 1)
+            ids2, lens2 = eng.transcribe_batch(pcm)
+            eng.set_option("skip_done", 0)
+            ids3, lens3 = eng.transcribe_batch(pcm)
+            eng.set_option("skip_done", 1)
+            eng.set_option("xattn_stream_from", 1024)
+            assert (ids2 == ids1).all() and (lens2 == lens1).all() and (ids3 == ids1).all() and (lens3 == lens1).all()
         if formats[0] == "f16":
             orc = WhisperOracle(dims, w)
             sel = np.arange(0, B, 5)
