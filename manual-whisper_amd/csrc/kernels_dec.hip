@@ -538,6 +538,24 @@ __global__ __launch_bounds__(kDecGemmWaves * 64) void gemm_dec_kernel(GemvParams
 #pragma unroll
     for (int c = 0; c < KR; ++c) wreg[c] = load16<kNtGemv>(wp + min(c, nk - 1) * 64);
     const int pos = (p.out_mode == GV_QKV && p.st) ? p.st->pos : 0;     // read here: no round trip of its own later
+    // epilogue operands of this lane's four columns, requested behind the weights: bias, weight scales and (residual
+    // outputs) the rows this tile is added to.  Only the workgroup that merges uses them, but it is the one whose
+    // round trips are the launch's critical path, and nobody else writes these rows during the launch.
+    const int n_ep = n0 + rt * 16 + 4 * fg;
+    const bool n_ok = n_ep < p.N;
+    float4 bias4 = make_float4(0, 0, 0, 0), ws4 = make_float4(1, 1, 1, 1);
+    float4 res4[TPW];
+    if (n_ok) {
+        if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n_ep);
+        if constexpr (W8) ws4 = *reinterpret_cast<const float4*>(p.w_scale + n_ep);
+        if (p.out_mode == GV_RESID) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int m = min((mg * TPW + t) * 16 + fr, p.B - 1);
+                res4[t] = *reinterpret_cast<const float4*>(p.out32 + (long)m * p.N + n_ep);
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the compiler does not count the LDS-DMA
     __syncthreads();
     const char* xs = smem;
@@ -603,10 +621,8 @@ __global__ __launch_bounds__(kDecGemmWaves * 64) void gemm_dec_kernel(GemvParams
         }
         if (tid == 0) __hip_atomic_store(p.sk_tickets + rg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
-    const int n = n0 + rt * 16 + 4 * fg;
-    if (n >= p.N) return;
-    const float4 bias4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
-    const float4 ws4 = W8 ? *reinterpret_cast<const float4*>(p.w_scale + n) : make_float4(1, 1, 1, 1);
+    const int n = n_ep;
+    if (!n_ok) return;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int m = (mg * TPW + t) * 16 + fr;
@@ -616,9 +632,8 @@ __global__ __launch_bounds__(kDecGemmWaves * 64) void gemm_dec_kernel(GemvParams
         if (n < p.scale_ncols) o *= p.scale;
         if (p.gelu) { o[0] = gelu_erf(o[0]); o[1] = gelu_erf(o[1]); o[2] = gelu_erf(o[2]); o[3] = gelu_erf(o[3]); }
         if (p.out_mode == GV_RESID) {
-            float4* dst = reinterpret_cast<float4*>(p.out32 + (long)m * p.N + n);
-            const float4 r4 = *dst;
-            *dst = make_float4(r4.x + o[0], r4.y + o[1], r4.z + o[2], r4.w + o[3]);
+            const float4 r4 = res4[t];
+            *reinterpret_cast<float4*>(p.out32 + (long)m * p.N + n) = make_float4(r4.x + o[0], r4.y + o[1], r4.z + o[2], r4.w + o[3]);
         } else {
             const half4 h = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
             if (p.out_mode == GV_F16) {
