@@ -250,7 +250,7 @@ int mw_profile_decode_gemvs(mw_ctx* ctx, int batch, int iters, float* mean_ms_pe
  * "skip_done" (1 = the decode cross-attention does not read the K/V cache of sequences that have ended, or of
  * recordings whose beam search is complete: their next token is end-of-text whatever the step computes;
  * default 1),
- * "xattn_stream_from" (number of (sequence, head) pairs from which the fp16 decode cross-attention runs as one
+ * "xattn_stream_from" (number of (sequence, head) pairs from which the decode cross-attention runs as one
  * workgroup per pair that walks all 1500 keys, instead of four key ranges per pair merged by the last to finish:
  * large decode groups fill the GPU without the ranges and their hand-off costs bandwidth; default 1024,
  * 0 = never). */

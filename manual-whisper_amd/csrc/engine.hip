@@ -859,7 +859,7 @@ static void cross_attention(mw_ctx* ctx, int li, const f16* q, f16* out, int row
         const size_t per_layer_rows = (size_t)ctx->max_batch * d.n_audio_ctx * d.n_heads;
         launch_dec_cross_attn8(q, ctx->crossK8 + li * per_layer, ctx->crossV8 + li * per_layer, ctx->crossKs + li * per_layer_rows,
                                ctx->crossVs + li * per_layer_rows, out, rows, d.n_heads, d.n_audio_ctx, ctx->xpartial, ctx->xtickets,
-                               ctx->stream, kv_div, row0, done, done_div);
+                               ctx->stream, kv_div, row0, done, done_div, ctx->xattn_stream_from);
     } else {
         launch_dec_cross_attn(q, ctx->crossK + li * per_layer, ctx->crossV + li * per_layer, out, rows, d.n_heads, d.n_audio_ctx,
                               ctx->xpartial, ctx->xtickets, ctx->stream, kv_div, row0, done, done_div, ctx->xattn_stream_from);

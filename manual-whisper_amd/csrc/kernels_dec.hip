@@ -962,11 +962,23 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(const f16* __restrict__ q,
 // flight; the only barrier is the one before the final merge of the four waves.  Every thread keeps its own
 // reference maximum (the 8 lanes of a row share it), merged at the end in a fixed order: lanes by butterfly, waves
 // in index order.
-template <bool DONE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void cross_attn_stream_kernel(
-    const f16* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc, f16* __restrict__ out, int H, int T,
-    const int* __restrict__ done, int done_div) {
+// KV8: the cache holds e4m3 codes [B][H][T][64] with one fp32 scale per row (cross_attn8_kernel's format):
+// score = (q . codes) * k_scale, output += p * v_scale * codes; eight rows a thread are 8 + 4 bytes each.
+template <bool KV8> struct XRow { half8 d; };
+template <> struct XRow<true> { uint2 d; float s; };
+__device__ __forceinline__ void xrow_f32(const XRow<false>& r, float (&f)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)r.d[j];
+}
+__device__ __forceinline__ void e4m3x8_to_f32(const uint2& w, float (&f)[8]);      // defined with the e4m3 kernels below
+__device__ __forceinline__ void xrow_f32(const XRow<true>& r, float (&f)[8]) { e4m3x8_to_f32(r.d, f); }
+
+template <bool DONE, bool KV8>
+__device__ __forceinline__ void cross_attn_stream_body(
+    const f16* __restrict__ q, const void* __restrict__ kc, const void* __restrict__ vc, const float* __restrict__ ks,
+    const float* __restrict__ vs, f16* __restrict__ out, int H, int T, const int* __restrict__ done, int done_div) {
     constexpr int NG = 32, RPT = 8, CH = NG * RPT, NWV = 4;
+    constexpr int EB = KV8 ? 1 : 2;                       // bytes per cached element
     __shared__ float wm[NWV], wl[NWV], wo[NWV][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = DONE ? blockIdx.y * H + blockIdx.x : blockIdx.x;
@@ -974,20 +986,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (done[blockIdx.y / done_div]) return;          // an ended sequence: its token is fixed whatever this computes
     }
     const int rg = tid >> 3, dc = tid & 7;
-    // workgroup-uniform bases and 32-bit element offsets (a sequence's head is T * 64 < 2^31 elements)
-    const f16* kb = kc + (long)bh * T * 64;
-    const f16* vb = vc + (long)bh * T * 64;
-    auto row_off = [&](int c, int i) -> unsigned { return (unsigned)(min(c * CH + rg + NG * i, T - 1) * 64 + dc * 8); };
-    half8 kv[RPT], vv[RPT];
+    // workgroup-uniform bases and 32-bit offsets (a sequence's head is T * 64 < 2^31 elements)
+    const char* kb = reinterpret_cast<const char*>(kc) + (long)bh * T * 64 * EB;
+    const char* vb = reinterpret_cast<const char*>(vc) + (long)bh * T * 64 * EB;
+    const float* ksb = KV8 ? ks + (long)bh * T : nullptr;
+    const float* vsb = KV8 ? vs + (long)bh * T : nullptr;
+    auto row_of = [&](int c, int i) -> int { return min(c * CH + rg + NG * i, T - 1); };
+    auto fetch = [&](const char* base, const float* sb, int c, int i) {
+        XRow<KV8> r;
+        const int row = row_of(c, i);
+        const char* src = base + (unsigned)((row * 64 + dc * 8) * EB);
+        if constexpr (KV8) { r.d = load8<kNtXattn>(src); r.s = sb[row]; }
+        else r.d = load_half8<kNtXattn>(src);
+        return r;
+    };
+    XRow<KV8> kv[RPT], vv[RPT];
     // the query first (loads retire in order: requested last it would be waited for behind the whole first chunk),
     // then the first chunk: all K rows, then all V rows, in the order the loop issues them
     const half8 qh = *reinterpret_cast<const half8*>(q + (long)bh * 64 + dc * 8);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) kv[i] = load_half8<kNtXattn>(kb + row_off(0, i));
+    for (int i = 0; i < RPT; ++i) kv[i] = fetch(kb, ksb, 0, i);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) vv[i] = load_half8<kNtXattn>(vb + row_off(0, i));
+    for (int i = 0; i < RPT; ++i) vv[i] = fetch(vb, vsb, 0, i);
     __builtin_amdgcn_sched_barrier(0);
     float qv[8];
 #pragma unroll
@@ -1005,18 +1027,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         float cm = -3.0e38f;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
+            float f[8];
+            xrow_f32(kv[i], f);
             float d = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d += qv[j] * (float)kv[i][j];
+            for (int j = 0; j < 8; ++j) d += qv[j] * f[j];
             d += __shfl_xor(d, 1);
             d += __shfl_xor(d, 2);
             d += __shfl_xor(d, 4);
+            if constexpr (KV8) d *= kv[i].s;
             sv[i] = (c * CH + rg + NG * i < T) ? d : -3.0e38f;
             cm = fmaxf(cm, sv[i]);
         }
-        if constexpr (MORE) {
+        if constexpr (MORE) {               // (pinned between the two halves: the scheduler would move them to the chunk's end)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < RPT; ++i) kv[i] = load_half8<kNtXattn>(kb + row_off(c + 1, i));
+            for (int i = 0; i < RPT; ++i) kv[i] = fetch(kb, ksb, c + 1, i);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- running softmax of this thread's rows (a thread whose rows are all masked keeps its state: exp(-huge) = 0)
         const float mn = fmaxf(m, cm);
@@ -1028,13 +1055,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int i = 0; i < RPT; ++i) {
             const float pr = __expf(sv[i] - mn);
             l += pr;
+            float f[8];
+            xrow_f32(vv[i], f);
+            float w = pr;
+            if constexpr (KV8) w *= vv[i].s;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += pr * (float)vv[i][j];
+            for (int j = 0; j < 8; ++j) acc[j] += w * f[j];
         }
         m = mn;
         if constexpr (MORE) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < RPT; ++i) vv[i] = load_half8<kNtXattn>(vb + row_off(c + 1, i));
+            for (int i = 0; i < RPT; ++i) vv[i] = fetch(vb, vsb, c + 1, i);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     for (int c = 0; c + 1 < nch; ++c) chunk(c, std::true_type{});
@@ -1069,6 +1102,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         O += a * wo[w][lane];
     }
     out[(long)bh * 64 + lane] = (f16)(O / L);
+}
+
+// fp16 cache: 116 registers, four workgroups per CU.  e4m3 cache: its row scales and code expansion need more than
+// 128 registers (held to 128 it spills), three per CU.
+template <bool DONE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void cross_attn_stream_kernel(
+    const f16* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc, f16* __restrict__ out, int H, int T,
+    const int* __restrict__ done, int done_div) {
+    cross_attn_stream_body<DONE, false>(q, kc, vc, nullptr, nullptr, out, H, T, done, done_div);
+}
+template <bool DONE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void cross_attn8_stream_kernel(
+    const f16* __restrict__ q, const uint8_t* __restrict__ kc, const uint8_t* __restrict__ vc, const float* __restrict__ ks,
+    const float* __restrict__ vs, f16* __restrict__ out, int H, int T, const int* __restrict__ done, int done_div) {
+    cross_attn_stream_body<DONE, true>(q, kc, vc, ks, vs, out, H, T, done, done_div);
 }
 
 // ------------------------------------------------------------------ cross-attention over an e4m3 cache
@@ -2061,7 +2109,16 @@ void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, De
 }
 
 void launch_dec_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
-                            int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div) {
+                            int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div,
+                            int stream_from_arg) {
+    // decode groups: one workgroup per (sequence, head) walking all keys, as launch_dec_cross_attn
+    static const int stream_from_env = getenv("MW_XSTREAM_FROM") ? atoi(getenv("MW_XSTREAM_FROM")) : -1;
+    const int stream_from = stream_from_env >= 0 ? stream_from_env : stream_from_arg;
+    if (kv_div == 1 && stream_from > 0 && (long)B * H >= stream_from) {
+        if (done) hipLaunchKernelGGL(cross_attn8_stream_kernel<true>, dim3(H, B), dim3(256), 0, s, q, k8, v8, ks, vs, out, H, T, done, done_div);
+        else hipLaunchKernelGGL(cross_attn8_stream_kernel<false>, dim3(B * H), dim3(256), 0, s, q, k8, v8, ks, vs, out, H, T, done, done_div);
+        return;
+    }
     // 4 key ranges of 375 frames; 256 threads = 32 row groups x 12 rows = 384 >= 375
     const dim3 g1(B * H * kXattnSplit), g2(H * kXattnSplit, B);
 #define MW_X8(GRP, DONE, GRID, KVD, R0) hipLaunchKernelGGL((cross_attn8_kernel<256, 12, kXattnSplit, GRP, DONE>), GRID, dim3(256), 0, s, q, k8, \

@@ -168,7 +168,7 @@ void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out,
 // The same over an e4m3 cache: k8, v8 [B][H][T][64] codes, ks, vs [B][H][T] row scales
 void launch_dec_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
                             int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div = 1, int row0 = 0,
-                            const int* done = nullptr, int done_div = 1);
+                            const int* done = nullptr, int done_div = 1, int stream_from = 1024);
 constexpr int kPrefillSlabRows = 256;      // query rows per cross-attention launch of the prompt prefill
 
 struct FinalizeParams {

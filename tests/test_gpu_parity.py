@@ -260,7 +260,7 @@ def test_ended_sequences_are_skipped_without_changing_ids(B, formats):
         ids1, lens1 = eng.transcribe_batch(pcm)
         assert (ids0 == ids1).all() and (lens0 == lens1).all()
         assert (lens1 == 0).any() and (lens1 > 0).any()            # some ended at once, some ran on
-        if formats[1] == "f16":
+        if True:
             # the cross-attention form of large decode groups (one workgroup per (sequence, head) walking all keys),
             # forced at this size, with and without the ended flags: same ids
             eng.set_option("xattn_stream_from", 1)
