@@ -424,8 +424,9 @@ def main(argv=None):
             "decode_steps_per_step": int(stage.get("decode_steps", 0)),
             "stage_roofline": stage_rooflines(dims, batch, len(opts.prompt), NEW_TOKENS, solo_ms, 1 if args.weights == "fp8" else 2, args.kv == "fp8"),
             "whole_run": None,
-            "roofline": {"kernel": (("cross_attn_stream_kernel" if (grouped and batch * args.group * dims.n_heads >= 1024) else "dec_attn_kernel<256,12,4>")
-                                    if args.kv == "f16" else "cross_attn8_kernel<256,12,4>")
+            "roofline": {"kernel": (("cross_attn_stream_kernel" if args.kv == "f16" else "cross_attn8_stream_kernel")
+                                    if (grouped and batch * args.group * dims.n_heads >= 1024) else
+                                    ("dec_attn_kernel<256,12,4>" if args.kv == "f16" else "cross_attn8_kernel<256,12,4>"))
                                    + " (decode cross-attention, one launch per layer per token)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "sequences": ca_seqs,
