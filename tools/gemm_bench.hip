@@ -110,6 +110,7 @@ int main(int argc, char** argv) {
         p.out_mode = OUT_RESID_F32; p.C = resid;
     }
     hipStream_t s; CK(hipStreamCreate(&s));
+    if (getenv("MW_GB_LDA0")) p.lda = 0;             // every A row is row 0 (always cached): isolates the A operand's memory latency; the check then fails
     launch_gemm(p, s);
     CK(hipStreamSynchronize(s));
     long bad = 0;
@@ -193,5 +194,25 @@ int main(int argc, char** argv) {
     }
 #endif
     printf("M=%d N=%d K=%d: %.1f us, %.1f TFLOP/s\n", M, N, K, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
+    if (getenv("MW_GB_DUAL") && !qkv) {
+        // the same product on two streams at once (second output buffer): time per launch when two launches share the GPU
+        GemmParams p2 = p;
+        void* c2 = nullptr;
+        CK(hipMalloc(&c2, (size_t)M * N * (rsd ? 4 : 2))); CK(hipMemset(c2, 0, (size_t)M * N * (rsd ? 4 : 2)));
+        p2.C = (f16*)c2;
+        hipStream_t s2; CK(hipStreamCreate(&s2));
+        hipEvent_t f0, f1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
+        for (int i = 0; i < 3; ++i) { launch_gemm(p, s); launch_gemm(p2, s2); }
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, s)); CK(hipEventRecord(f0, s2));
+        for (int i = 0; i < iters; ++i) { launch_gemm(p, s); launch_gemm(p2, s2); }
+        CK(hipEventRecord(e1, s)); CK(hipEventRecord(f1, s2));
+        CK(hipDeviceSynchronize());
+        float ma, mb, span; CK(hipEventElapsedTime(&ma, e0, e1)); CK(hipEventElapsedTime(&mb, f0, f1));
+        CK(hipEventElapsedTime(&span, e0, f1));
+        span = fmaxf(span, ma);
+        printf("  two streams: %.1f / %.1f us per launch on each, %.1f us per launch overall (%.1f TFLOP/s)\n", ma / iters * 1e3, mb / iters * 1e3,
+               span / (2 * iters) * 1e3, 2.0 * M * N * K / (span / (2 * iters) * 1e-3) / 1e12);
+    }
     return bad ? 2 : 0;
 }
