@@ -6,8 +6,10 @@ fixed 30 s chunks (the last one zero-padded) and a segment's start/end are its c
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 from typing import List, Optional, Sequence, Tuple
 
@@ -125,6 +127,8 @@ class GroupedPool:
         self._free_enc: "queue.Queue" = queue.Queue()
         for e in self.encoders:
             self._free_enc.put(e)
+        # development aid: (kind, index, start, end) of every encoder pass and decode loop of the last map(), host clock
+        self.trace: Optional[list] = [] if os.environ.get("MW_POOL_TRACE") else None
 
     @property
     def engines(self):
@@ -134,11 +138,18 @@ class GroupedPool:
         for e in {id(e): e for e in [self.root] + self.engines}.values():
             e.set_decode_options(opts)
 
-    def map(self, batches: Sequence) -> list:
+    def map(self, batches: Sequence, sizes: Optional[Sequence[int]] = None) -> list:
         """Transcribe every batch (numpy on the host or a tensor on the engine's GPU, at most `batch` chunks each);
-        returns [(ids, lens)] in the order of ``batches``."""
+        returns [(ids, lens)] in the order of ``batches``.  ``sizes``: batches per decode group, in order (each at
+        most `group`, summing to ``len(batches)``); default: `group_sizes`."""
         n = len(batches)
-        sizes = group_sizes(n, self.group)
+        if self.trace is not None:
+            self.trace.clear()
+        if sizes is None:
+            sizes = group_sizes(n, self.group)
+        sizes = [int(x) for x in sizes]
+        if sum(sizes) != n or any(x < 1 or x > self.group for x in sizes):
+            raise ValueError(f"group sizes {sizes} do not split {n} batches into groups of 1..{self.group}")
         n_groups, nd = len(sizes), len(self.decoders)
         group_of, slot_of, members = [], [], []
         i = 0
@@ -167,10 +178,13 @@ class GroupedPool:
                 if errors:
                     return
                 enc = self._free_enc.get()
+                t_start = time.perf_counter()
                 try:
                     enc.encode_into(batches[i], self.decoders[g % nd], slot_of[i])
                 finally:
                     self._free_enc.put(enc)
+                    if self.trace is not None:
+                        self.trace.append(("encode", i, t_start, time.perf_counter()))
             except BaseException as e:         # noqa: BLE001 - handed to the caller below
                 errors.append(e)
             finally:
@@ -184,7 +198,10 @@ class GroupedPool:
                 if not errors:
                     rows = sum(int(batches[i].shape[0]) for i in members[g])
                     dec.set_encoded(rows)
+                    t_start = time.perf_counter()
                     ids, lens, _ = dec.decode_greedy(rows)
+                    if self.trace is not None:
+                        self.trace.append(("decode", g, t_start, time.perf_counter()))
                     for i in members[g]:
                         a, b = slot_of[i], slot_of[i] + int(batches[i].shape[0])
                         results[i] = (ids[a:b].copy(), lens[a:b].copy())

@@ -592,6 +592,15 @@ def test_grouped_pool_encodes_in_batches_and_decodes_in_groups():
             for (a, b), (ids, lens) in zip(cuts, got):
                 wi, wl = plain.transcribe_batch(pcm[a:b])
                 assert ids.shape == wi.shape and (ids == wi).all() and (lens == wl).all(), (a, b)
+        # the caller's own split into decode groups (1, 3, 2, 2 batches instead of 3, 3, 2): same ids
+        cuts = [(0, 4), (4, 8), (8, 12), (12, 16), (16, 20), (20, 24), (24, 28), (28, 30)]
+        got = pool.map([pcm[a:b] for a, b in cuts], sizes=[1, 3, 2, 2])
+        for (a, b), (ids, lens) in zip(cuts, got):
+            wi, wl = plain.transcribe_batch(pcm[a:b])
+            assert (ids == wi).all() and (lens == wl).all(), (a, b)
+        for bad in ([4, 4], [3, 3, 3], [3, 3, 2, 0]):
+            with pytest.raises(ValueError):
+                pool.map([pcm[a:b] for a, b in cuts], sizes=bad)
         assert pool.map([]) == []
         with pytest.raises(ValueError):
             pool.map([pcm[:5]])
