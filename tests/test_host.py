@@ -52,6 +52,77 @@ def test_group_sizes():
             assert sum(sz) == n and max(sz) <= g and max(sz) - min(sz) <= 1 and len(sz) == (n + g - 1) // g
 
 
+class _StandInEngine:
+    """Host-only stand-in for engine.Engine in GroupedPool: an "encoder pass" writes each chunk's first sample into
+    the decode engine's slots, a "decode loop" returns them; the log records who did what, in which order."""
+    def __init__(self, max_batch, log):
+        self.max_batch, self.log, self.slots, self.rows = max_batch, log, {}, 0
+
+    def fork(self, batch):
+        return _StandInEngine(batch, self.log)
+
+    def set_decode_options(self, opts):
+        pass
+
+    def encode_into(self, pcm, dst, slot0):
+        assert pcm.shape[0] <= self.max_batch
+        for r in range(pcm.shape[0]):
+            dst.slots[slot0 + r] = int(pcm[r, 0])
+        self.log.append(("encode", id(dst), slot0, pcm.shape[0]))
+
+    def set_encoded(self, rows):
+        self.rows = rows
+
+    def decode_greedy(self, rows):
+        assert rows == self.rows and rows <= self.max_batch and sorted(self.slots)[:rows] == list(range(rows))
+        ids = np.array([[self.slots[r]] for r in range(rows)], np.int32)
+        self.log.append(("decode", id(self), rows))
+        self.slots = {}
+        return ids, np.ones(rows, np.int32), None
+
+    def close(self):
+        pass
+
+
+def test_grouped_pool_order_and_group_split(monkeypatch):
+    """GroupedPool on stand-in engines: every batch comes back in its place whatever the split into decode groups,
+    a decode engine's cache is refilled only after its previous group has been decoded, and the optional trace lists
+    every encoder pass and decode loop."""
+    monkeypatch.setenv("MW_POOL_TRACE", "1")
+    log = []
+    pool = scheduler.GroupedPool(_StandInEngine(4, log), batch=4, group=3, n_encoders=2, n_decoders=2)
+    try:
+        batches = [np.full((4 if i % 3 else 2, 8), 100 + i, np.float32) for i in range(11)]
+        for sizes in (None, [1, 3, 2, 3, 2], [3, 3, 3, 2]):
+            del log[:]
+            got = pool.map(batches, sizes=sizes)
+            assert [int(ids[0, 0]) for ids, _ in got] == [100 + i for i in range(11)]
+            assert all(ids.shape[0] == b.shape[0] for (ids, _), b in zip(got, batches))
+            want = sizes or scheduler.group_sizes(11, 3)
+            assert sorted(k for k, *_ in pool.trace) == ["decode"] * len(want) + ["encode"] * 11
+            # per decode engine: encoder passes, a decode loop, encoder passes, a decode loop: never a pass into a cache
+            # still to be decoded; the two encoders finish in any order, and the passes of a group tile its slots
+            for dec in pool.decoders:
+                pieces = []
+                for e in log:
+                    if e[0] == "encode" and e[1] == id(dec):
+                        pieces.append((e[2], e[3]))
+                    elif e[0] == "decode" and e[1] == id(dec):
+                        at = 0
+                        for slot0, rows in sorted(pieces):
+                            assert slot0 == at
+                            at += rows
+                        assert e[2] == at
+                        pieces = []
+                assert pieces == []
+        for bad in ([3, 3, 3, 3], [4, 4, 3], [11], [3, 3, 3, 2, 0]):
+            with pytest.raises(ValueError):
+                pool.map(batches, sizes=bad)
+        assert pool.map([]) == []
+    finally:
+        pool.close()
+
+
 def test_shard_and_pack():
     for n in (0, 1, 7, 120):
         for w in (1, 2, 8):
