@@ -1,4 +1,4 @@
-# Round-2 profile set (run on the GPU box from the repo root): rocprofv3 kernel stats of the bench commands and
+# Profile set behind profiles/round2_*.csv (run on the GPU box from the repo root): rocprofv3 kernel stats of the bench commands and
 # FETCH_SIZE / WRITE_SIZE passes (one run each) of tools/pmc_probe.py at 16 and at 112 sequences.
 set -e
 cd /tmp && export TMPDIR=/tmp
