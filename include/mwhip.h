@@ -133,15 +133,18 @@ const char* mw_last_error(const mw_ctx* ctx);
  * context for mw_encode. */
 int mw_logmel(mw_ctx* ctx, const float* pcm, int batch, float* mel_out);
 
-/* mw_logmel for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc): no counterpart in the reference.  pcm float32 [batch][480000] and
+/* mw_logmel for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc): no counterpart in the reference.  It synchronises its own stream and reads its events before it
+ * returns, so it cannot itself be captured into a HIP graph.  pcm float32 [batch][480000] and
  * mel_out float32 [batch][n_mels][3000] must both be device memory of the context's GPU (a host buffer would
  * need staging, which allocates) and both are required; the features also stay in the context for mw_encode.
  * The call allocates and frees nothing, on the device or through any library: the only memory its kernels use
  * beyond pcm, mel_out and the context's tables is a file-scope __device__ array in the library (one copy per
  * GPU, 128 chunks x 94 block maxima x 4 B = 47 KiB, held until the process ends).  batch beyond 128 is
- * refused (MW_ERR_ARG).  All contexts of one GPU share that array: calls of this entry point that overlap on
- * one GPU race; serialise them.  Results are bit-identical to mw_logmel. */
+ * refused (MW_ERR_ARG).  All contexts of one GPU share that array: calls of this entry point on one GPU take
+ * turns (a per-GPU lock inside the library is held for the duration of the call, which blocks until its two
+ * launches are done); from several processes on one GPU every process has its own copy.  Results are bit-identical
+ * to mw_logmel. */
 int mw_logmel_noalloc(mw_ctx* ctx, const float* pcm, int batch, float* mel_out);
 
 /* Stage 2: encoder + per-layer cross-attention K/V for the decoder.

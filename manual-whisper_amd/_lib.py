@@ -45,6 +45,62 @@ class AlignDesc(C.Structure):
 
 _lib = None
 
+# Hardware queues.  Every engine stream wants a hardware queue of its own: the default arrangement opens 2 encoder
+# and 3 decode engine streams beside the root engine's and torch's, and with HIP's default of 4 queues per process
+# (GPU_MAX_HW_QUEUES, which the environment may also spell out) streams share queues and their launches serialise
+# behind each other's (2057 -> 1842 audio-s/s measured with a fourth engine on a shared queue).  The HIP runtime
+# reads the variable once, when it starts, so it has to be in the environment before anything makes a HIP call.
+DEFAULT_HW_QUEUES = 8
+MAX_HW_QUEUES = 32
+_hw_queues = {"effective": None, "late": False}
+
+
+def _hip_runtime_mapped() -> bool:
+    try:
+        with open("/proc/self/maps", encoding="ascii", errors="replace") as f:
+            return any("libamdhip64" in line for line in f)
+    except OSError:
+        return False
+
+
+def configure_hw_queues() -> int:
+    """Put GPU_MAX_HW_QUEUES into the environment (MW_HW_QUEUES, default 8, at most 32) unless a HIP runtime is
+    already mapped into the process, in which case what it started with stands.  Called when the package is
+    imported and again before the library is loaded; returns the number of queues the process will have."""
+    if _hw_queues["effective"] is not None:
+        return _hw_queues["effective"]
+    try:
+        want = int(os.environ.get("MW_HW_QUEUES", DEFAULT_HW_QUEUES))
+    except ValueError:
+        want = DEFAULT_HW_QUEUES
+    want = max(1, min(MAX_HW_QUEUES, want))
+    if _hip_runtime_mapped():
+        # someone (torch, most likely) loaded the runtime first.  If it has not made its first HIP call yet the
+        # variable still takes effect, so it is raised all the same; what is counted on is the value it had
+        try:
+            have = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        except ValueError:
+            have = 4
+        if have < want:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(want)
+        _hw_queues.update(effective=have, late=True)
+        return have
+    os.environ["GPU_MAX_HW_QUEUES"] = str(want)
+    _hw_queues.update(effective=want, late=False)
+    return want
+
+
+def check_hw_queues(n_streams: int) -> None:
+    """Warn when an arrangement opens more engine streams (+ torch's own) than the process has hardware queues."""
+    have = configure_hw_queues()
+    if n_streams + 1 > have:
+        import warnings
+        why = ("the HIP runtime was loaded before manual_whisper_amd was imported, so GPU_MAX_HW_QUEUES may not have been raised "
+               "in time: import manual_whisper_amd (or set GPU_MAX_HW_QUEUES) before torch") if _hw_queues["late"] else \
+              "raise MW_HW_QUEUES (at most 32)"
+        warnings.warn(f"{n_streams} engine streams on {have} hardware queues: streams share queues and their launches "
+                      f"serialise; {why}", RuntimeWarning, stacklevel=3)
+
 
 def _share_torch_hip_runtime():
     """One HIP runtime per process.
@@ -76,6 +132,7 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m manual_whisper_amd.build` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    configure_hw_queues()           # before any HIP runtime is mapped by this package
     _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p

@@ -31,6 +31,8 @@ static __device__ __align__(256) float scratch[kNoAllocMaxBatch * kMelBlocksPerC
 constexpr int kMaxDevices = 64;
 static float* g_scratch_ptr[kMaxDevices] = {};
 static std::mutex g_scratch_mutex;
+// one per GPU: every context and fork on a GPU shares that GPU's array, so calls on one GPU take turns
+static std::mutex g_scratch_in_use[kMaxDevices];
 
 // `device` must be current.  Returns hipSuccess once the device's address is known.
 static hipError_t resolve_scratch(int device) {
@@ -704,6 +706,9 @@ extern "C" int mw_logmel_noalloc(mw_ctx* ctx, const float* pcm, int batch, float
         return fail(ctx, MW_ERR_ARG, "mw_logmel_noalloc: pcm and mel_out must be device memory (staging host buffers would allocate)");
     float* blockmax = g_scratch_ptr[ctx->device];           // resolved by mw_create on this device
     if (!blockmax) return fail(ctx, MW_ERR_STATE, "mw_logmel_noalloc: the scratch address of this device was never resolved");
+    // held until this call's two launches have finished (the call blocks on its stream anyway): two engine threads on
+    // one GPU would otherwise overwrite each other's block maxima
+    std::lock_guard<std::mutex> in_use(g_scratch_in_use[ctx->device]);
     MelTables t{ctx->basis_cos, ctx->basis_sin, ctx->filt, ctx->d.n_mels, ctx->n_mels_pad};
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     launch_mel_dft(pcm, batch, t, mel_out, blockmax, ctx->stream);           // writes every maximum it later reads: nothing to clear
@@ -1264,11 +1269,17 @@ extern "C" int mw_decode_sample(mw_ctx* ctx, int n_audio, int best_of, float tem
     HIPCHK(hipSetDevice(ctx->device));
     const mw_model_desc& d = ctx->d;
     const int R = n_audio * best_of, P = (int)ctx->prompt.size(), max_new = ctx->max_new;
-    if (!ctx->ss) {                 // first use: sized for max_batch sequences
-        const size_t MB = ctx->max_batch;
-        ALLOC(ctx->ss, 1); ALLOC(ctx->sp_sum_lp, MB); ALLOC(ctx->sp_active, MB);
-        ALLOC(ctx->sp_part_m, MB * kBeamParts); ALLOC(ctx->sp_part_s, MB * kBeamParts); ALLOC(ctx->sp_part_v, MB * kBeamParts);
-        ALLOC(ctx->sp_part_l, MB * kBeamParts); ALLOC(ctx->sp_part_i, MB * kBeamParts);
+    if (!ctx->sp_part_i) {          // first use: sized for max_batch sequences.  Gated on the buffer allocated LAST, and
+        const size_t MB = ctx->max_batch;           // every buffer only if it is still missing: an allocation that failed
+        auto missing = [](const void* p) { return p == nullptr; };      // part-way is completed by the next call
+        if (missing(ctx->ss)) ALLOC(ctx->ss, 1);
+        if (missing(ctx->sp_sum_lp)) ALLOC(ctx->sp_sum_lp, MB);
+        if (missing(ctx->sp_active)) ALLOC(ctx->sp_active, MB);
+        if (missing(ctx->sp_part_m)) ALLOC(ctx->sp_part_m, MB * kBeamParts);
+        if (missing(ctx->sp_part_s)) ALLOC(ctx->sp_part_s, MB * kBeamParts);
+        if (missing(ctx->sp_part_v)) ALLOC(ctx->sp_part_v, MB * kBeamParts);
+        if (missing(ctx->sp_part_l)) ALLOC(ctx->sp_part_l, MB * kBeamParts);
+        ALLOC(ctx->sp_part_i, MB * kBeamParts);
     }
     int n_ended = 0;
     if (active) {

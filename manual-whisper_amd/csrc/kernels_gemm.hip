@@ -366,8 +366,10 @@ __device__ __forceinline__ void gemm256_epilogue_f16(const GemmParams& p, float4
     }
 }
 
+// MI = 8 (256x128 tile, 96 KiB of LDS, one workgroup per CU) is held to 256 registers: one wave per SIMD that leaves
+// half of the register file, 64 KiB of LDS and 12 wave slots per CU to kernels of other streams.
 template <int MI, bool GLDS, bool F8 = false>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, MI == 8 ? 2 : 1) void gemm_kernel(GemmParams p) {
     constexpr int BM = MI * 32;
     constexpr int STAGE = (BM + BN) * BK;                        // halfs per buffer: A tile then W tile
     extern __shared__ __attribute__((aligned(16))) f16 lds[];   // [2][STAGE]
@@ -473,12 +475,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
                                                  (__attribute__((address_space(3))) void*)(&wt[(wave * 4 + i) * 8 * BK]), 16, 0, 0);
         };
+        if constexpr (MI == 8) {
+            // three buffers, two K-tiles in flight while one is multiplied: a wave waits for its own DMA of tile kt
+            // (all but the MI + 4 instructions of tile kt + 1 retired), the barrier makes every wave's part of it
+            // visible and says that everyone is done reading tile kt - 1, whose buffer tile kt + 2 then takes
+            stage(0, 0);
+            if (nk > 1) stage(1, BK);
+            int buf = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + 2 < nk) stage(buf >= 1 ? buf - 1 : 2, (kt + 2) * BK);
+                compute(buf);
+                buf = buf == 2 ? 0 : buf + 1;
+            }
+        } else {
         stage(0, 0);
         __syncthreads();                       // drains the LDS-DMA (vmcnt(0)) before anyone reads
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
             compute(kt & 1);
             __syncthreads();
+        }
         }
     } else {
         // staging through registers (any K that is a multiple of 8, zero fill): MI = 4 only
@@ -532,9 +551,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 template <int MI, bool GLDS, bool F8 = false>
 void launch_t(const GemmParams& p, hipStream_t s) {
     constexpr int BM = MI * 32;
-    constexpr size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(f16);
+    // MW_GEMM_LDS_PAD (tuning runs): extra bytes of LDS request that nothing uses, to hold the kernel to one workgroup per CU
+    static const size_t pad = getenv("MW_GEMM_LDS_PAD") ? (size_t)atoi(getenv("MW_GEMM_LDS_PAD")) : 0;
+    const size_t lds = (size_t)(MI == 8 ? 3 : 2) * (BM + BN) * BK * sizeof(f16) + pad;
     static std::once_flag prepared;     // raise the dynamic-LDS limit once, whichever engine thread gets here first
-    std::call_once(prepared, [] {
+    std::call_once(prepared, [lds] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MI, GLDS, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     const int nt = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -830,10 +851,12 @@ void launch_gemm(const GemmParams& p0, hipStream_t s) {
     // MI = 8 (256-row tile, one workgroup per CU) measured 35 % slower than MI = 4 (two per CU): with a
     // single barrier-synchronised workgroup on a CU nothing covers its waits.
     static const bool no256 = getenv("MW_GEMM_NO256") != nullptr;
+    static const bool share = getenv("MW_GEMM_CS") != nullptr;          // tuning runs: the CU-sharing 256x128 form for every big product
     const int nk = p.K / BK;
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (p.K % BK != 0) launch_t<4, false>(p, s);
     else if (p.groups > 1) launch_t<4, true>(p, s);                  // grouped products: the 128x128 form only
+    else if (share && tiles256 >= 256) launch_t<8, true>(p, s);
     else if (!no256 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256 && p.N % 8 == 0) launch_256<false>(p, s);
     else launch_t<4, true>(p, s);
 }

@@ -104,22 +104,30 @@ class Model:
                 self._pool_key = ("coalesced",)
             return self.pool
         n_batches = max(1, -(-n_chunks // batch_size))
+        have = self._pool_key
+        kept = self.pool is not None and have[0] == "grouped"
+        # a pool whose encoder engines take larger batches serves smaller ones too
+        batch = max(batch_size, have[1]) if kept else batch_size
         # a decode engine holds its group's cross-attention K/V (0.25 GB per sequence at large-v3) and, like every
         # engine, encoder-sized workspaces: groups are kept to `max_group_sequences` so that three of them fit beside
         # the encoders whatever batch_size the caller picks
-        group = max(1, min(self.group, n_batches, max(1, self.max_group_sequences // batch_size)))
+        cap = max(1, self.max_group_sequences // batch)
+        group = max(1, min(self.group, n_batches, cap))
         n_groups = -(-n_batches // group)
-        need = (batch_size, group, min(self.n_encoders, n_batches), min(self.n_decoders, n_groups))
-        have = self._pool_key
-        if self.pool is not None and have[0] == "grouped" and all(h >= n for h, n in zip(have[1:], need)):
+        need = (batch, group, min(self.n_encoders, n_batches), min(self.n_decoders, n_groups))
+        if kept and all(h >= n for h, n in zip(have[1:], need)):
             return self.pool
         if self.pool is not None:
             self._close_pool()
-            need = tuple(max(h, n) for h, n in zip(have[1:], need)) if have[0] == "grouped" else need
-        self.pool = GroupedPool(self.engine, need[0], need[1], need[2], need[3])
+            if kept:        # keep what the old pool could do where the memory rule allows it (batch * group <= max_group_sequences)
+                need = (batch, max(1, min(max(have[2], group), cap)), max(have[3], need[2]), max(have[4], need[3]))
+        self.pool = self._make_grouped_pool(*need)
         self._pool_key = ("grouped",) + need
         self._opts_for = None
         return self.pool
+
+    def _make_grouped_pool(self, batch, group, n_encoders, n_decoders):
+        return GroupedPool(self.engine, batch, group, n_encoders, n_decoders)
 
     def _close_pool(self):
         """Close the pool's engines but keep the root engine (it owns the weights)."""

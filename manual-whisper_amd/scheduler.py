@@ -15,6 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import _lib
 from .dims import CHUNK_SAMPLES, CHUNK_SECONDS, SAMPLE_RATE
 
 
@@ -55,6 +56,7 @@ class EnginePool:
         self.detokenize = detokenize
         if self.fallback is not None and detokenize is None:
             raise ValueError("temperature fallback needs detokenize")
+        _lib.check_hw_queues(n_engines)              # one stream per engine
         self.engines = [engine] + [engine.fork() for _ in range(n_engines - 1)]
         self._free: "queue.Queue" = queue.Queue()
         for e in self.engines:
@@ -120,6 +122,7 @@ class GroupedPool:
         self.root = engine
         # the engine that owns the weights serves as the first encoder when its own workspaces are large enough
         first = [engine] if engine.max_batch >= batch else []
+        _lib.check_hw_queues(n_encoders + n_decoders + (0 if first else 1))       # one stream per engine, the root's included
         self.encoders = first + [engine.fork(batch) for _ in range(n_encoders - len(first))]
         self.decoders = [engine.fork(batch * group) for _ in range(n_decoders)]
         self._enc_pool = ThreadPoolExecutor(max_workers=n_encoders)

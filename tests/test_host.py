@@ -123,6 +123,59 @@ def test_grouped_pool_order_and_group_split(monkeypatch):
         pool.close()
 
 
+def test_model_pool_stays_within_the_sequence_cap_when_batch_size_changes():
+    """Model._pool_for over stand-in engines: transcribe(batch_size=16), then 64, then 128, then 16 again.  A decode
+    engine never holds more than max_group_sequences sequences (batch * group), a larger batch shrinks the group, and
+    a call the pool at hand can serve does not rebuild it."""
+    from manual_whisper_amd.model import Model
+    log, built = [], []
+
+    class _M(Model):
+        def _make_grouped_pool(self, batch, group, n_encoders, n_decoders):
+            built.append((batch, group, n_encoders, n_decoders))
+            return scheduler.GroupedPool(_StandInEngine(16, log), batch, group, n_encoders, n_decoders)
+
+    m = _M(_StandInEngine(16, log), mw.get_dims("micro"), "zh", arrangement="grouped", synthetic=True)
+    for bs, n_chunks in ((16, 320), (64, 640), (128, 640), (16, 320), (16, 40), (128, 128)):
+        pool = m._pool_for(n_chunks, bs)
+        batch, group = m._pool_key[1:3]
+        assert batch >= bs and batch * group <= m.max_group_sequences and len(pool.decoders) <= 3
+        assert pool.batch == batch and pool.group == group
+    assert built == [(16, 7, 2, 3), (64, 2, 2, 3), (128, 1, 2, 3)], built
+    m._close_pool()
+
+
+def test_hardware_queues_are_raised_before_torch_or_hip_load():
+    """The command line path (`import transcribe`, as `python transcribe.py x` does before main()) puts
+    GPU_MAX_HW_QUEUES into the environment before torch is imported or a HIP runtime is mapped: 8 by default whatever
+    the environment said, MW_HW_QUEUES to override, never above 32."""
+    probe = ("import os, sys\n"
+             f"sys.path.insert(0, {ROOT!r})\n"
+             "import transcribe\n"
+             "from manual_whisper_amd import _lib\n"
+             "assert 'torch' not in sys.modules and not _lib._hip_runtime_mapped()\n"
+             "print('queues', os.environ['GPU_MAX_HW_QUEUES'], _lib.configure_hw_queues())\n")
+    for env_in, want in (({"GPU_MAX_HW_QUEUES": "4"}, "8"), ({"MW_HW_QUEUES": "12"}, "12"), ({"MW_HW_QUEUES": "64"}, "32"),
+                         ({"MW_HW_QUEUES": "junk"}, "8")):
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "MW_HW_QUEUES")}
+        env.update(env_in)
+        r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0 and f"queues {want} {want}" in r.stdout, r.stdout + r.stderr
+
+
+def test_pools_warn_when_streams_outnumber_hardware_queues(monkeypatch):
+    from manual_whisper_amd import _lib
+    monkeypatch.setitem(_lib._hw_queues, "effective", 4)
+    monkeypatch.setitem(_lib._hw_queues, "late", True)
+    with pytest.warns(RuntimeWarning, match="hardware queues"):
+        scheduler.GroupedPool(_StandInEngine(4, []), batch=4, group=2, n_encoders=2, n_decoders=3).close()
+    monkeypatch.setitem(_lib._hw_queues, "effective", 8)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        scheduler.GroupedPool(_StandInEngine(4, []), batch=4, group=2, n_encoders=2, n_decoders=3).close()
+
+
 def test_shard_and_pack():
     for n in (0, 1, 7, 120):
         for w in (1, 2, 8):

@@ -7,7 +7,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("MW_HW_QUEUES", "8")
+# (the package raises GPU_MAX_HW_QUEUES itself when it is imported, before torch: _lib.configure_hw_queues)
 import numpy as np
 
 import manual_whisper_amd as mw
