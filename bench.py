@@ -29,7 +29,9 @@ import time
 # One hardware queue per engine stream (plus torch's own): with HIP's default of 4 (which the environment may
 # also spell out) the fourth engine shares a queue and its launches serialise behind another engine's:
 # 1842 audio-s/s against 2126 with 8 queues.  Must be set before the HIP runtime starts.  MW_HW_QUEUES overrides.
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("MW_HW_QUEUES", "8")
+# The package does the same when it is imported (manual_whisper_amd._lib.configure_hw_queues: the command line front
+# end and load_model get the same queues); bench.py imports torch first, so it says it here as well.
+os.environ["GPU_MAX_HW_QUEUES"] = str(max(1, min(32, int(os.environ.get("MW_HW_QUEUES", "8")))))
 
 import numpy as np
 
@@ -96,7 +98,7 @@ def stage_rooflines(dims, batch, n_prompt, n_new, ms, layer_weight_bytes=2, kv8=
     return out
 
 
-def cpu_baseline(dims, weights_np, opts, gpu_ids_fn, weight_format="f16", kv_format="f16"):
+def cpu_baseline(dims, weights_np, opts, gpu_ids_fn, weight_format="f16", kv_format="f16", gpu_ids_grouped_fn=None):
     """Oracle on the host: one 30 s chunk, 8 sampled tokens; decode time extrapolated to 128."""
     from threadpoolctl import threadpool_info
     from manual_whisper_amd import synth
@@ -121,6 +123,7 @@ def cpu_baseline(dims, weights_np, opts, gpu_ids_fn, weight_format="f16", kv_for
     t_steps = max(t3 - t2 - t_ckv, 1e-9)
     t_full = (t1 - t0) + (t2 - t1) + t_ckv + t_steps * steps_full / steps_sample
     gpu_ids = gpu_ids_fn(pcm, sample_new)
+    grouped_ids = gpu_ids_grouped_fn(pcm, sample_new) if gpu_ids_grouped_fn is not None else None
     threads = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
     return {
         "value": round(30.0 / t_full, 4), "unit": "audio-seconds/second", "cores": int(threads), "host_cpu_count": os.cpu_count(), "kind": "port",
@@ -129,6 +132,9 @@ def cpu_baseline(dims, weights_np, opts, gpu_ids_fn, weight_format="f16", kv_for
                    f"linearly to {steps_full} steps ({NEW_TOKENS} sampled tokens)"),
         "measured_seconds": round(t3 - t0, 2),
         "ids_match_gpu": bool((gpu_ids == ids).all()),
+        # the same chunk as sequence 0 of a decode group of 112 (the path the headline times: encode_into, gemm_dec_kernel,
+        # cross_attn_stream_kernel), the other 111 sequences being other audio
+        "ids_match_gpu_grouped": None if grouped_ids is None else bool((grouped_ids == ids).all()),
     }
 
 
@@ -211,7 +217,7 @@ def fp8_b32_run(dims, opts, dev, local_rank):
     return out
 
 
-def align_side_run(local_rank, n_seg=32):
+def align_side_run(local_rank, n_seg=48):
     """The step after the hot path in the reference (transcribe.py:127-135): forced alignment of every segment with a
     wav2vec2-large-xlsr-53-shaped CTC model (synthetic weights, vocabulary 3503), `n_seg` windows of 30 s with 150
     characters each through alignment.align()."""
@@ -225,7 +231,7 @@ def align_side_run(local_rank, n_seg=32):
     audio = np.tile(synth.hash_uniform_np(30 * 16000, "wave.bench", 5) * np.float32(0.6), n_seg)
     rng = np.random.default_rng(1)
     segs = [{"text": "".join(rng.choice(chars, 150)), "start": 30.0 * i, "end": 30.0 * (i + 1)} for i in range(n_seg)]
-    alignment.align(segs[:model.n_streams], model, meta, audio, "cuda")
+    alignment.align(segs[:8 * model.n_streams], model, meta, audio, "cuda")
     t = time.perf_counter()
     res = alignment.align(segs, model, meta, audio, "cuda")
     dt = time.perf_counter() - t
@@ -234,10 +240,213 @@ def align_side_run(local_rank, n_seg=32):
     one = time.perf_counter() - t
     model.close()
     return {"workload": f"alignment.align() over {n_seg} windows of 30 s x 150 characters, wav2vec2-large-xlsr-53 geometry (24 layers of 1024, "
-                        f"vocabulary {cfg['vocab_size']}), synthetic weights, {model.n_streams} segments in flight, host buffers in and out",
+                        f"vocabulary {cfg['vocab_size']}), synthetic weights, packs of up to {model.desc.max_samples // 480000} windows per pass of the model, "
+                        f"{model.n_streams} passes in flight, host buffers in and out",
             "value": round(n_seg * 30 / dt, 1), "unit": "audio-seconds/second", "ms_per_window": round(dt / n_seg * 1e3, 2),
             "one_window_alone_ms": round(one * 1e3, 2), "words": len(res["word_segments"]),
             "note": "outside the headline metric: the reference runs this after model.transcribe"}
+
+
+def make_model(eng, dims, opts, **kw):
+    """The call surface's Model over an engine that already holds the weights, with the benchmark's decode rules."""
+    from manual_whisper_amd.model import Model
+    m = Model(eng, dims, "zh", arrangement="grouped", synthetic=True, max_new=opts.max_new, **kw)
+    m.fixed_options = opts
+    return m
+
+
+def rank_share_run(eng, dims, opts, dev, batch):
+    """BASELINE configs[3] as written is ONE hour of audio (120 chunks of 30 s) split over the ranks: a rank's share is
+    15 / 30 / 60 / 120 chunks at N = 8 / 4 / 2 / 1.  Each share through Model.transcribe_ids_chunks (the arrangement
+    Model._pool_for picks for a job of that size), engines built and graphs captured by a first call, then idle GPU ->
+    ids on the host, best of two."""
+    import torch
+    from manual_whisper_amd import synth
+    model = make_model(eng, dims, opts)
+    pcm = synth.make_pcm_torch(120, seed=4242, device=dev)
+    torch.cuda.synchronize()
+    out = {"workload": "one rank's share of a 1 h recording (120 chunks of 30 s) at N = 8, 4, 2, 1 ranks, whole job from an idle GPU to "
+                       f"ids on the host, batch_size {batch}, {len(opts.prompt)} prompt + {opts.max_new} sampled tokens, PCM resident in HBM"}
+    for n in (15, 30, 60, 120):
+        model.transcribe_ids_chunks(pcm[:n], batch)
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(2):
+            t = time.perf_counter()
+            model.transcribe_ids_chunks(pcm[:n], batch)
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+        key = model._pool_key
+        out[f"{n}_chunks"] = {"ranks": 120 // n, "ms": round(best * 1e3, 1), "value": round(n * 30.0 / best, 1), "unit": "audio-seconds/second per GPU",
+                              "whole_recording_audio_s_per_s_at_that_many_ranks": round(120 * 30.0 / best, 1),
+                              "arrangement": {"batch": key[1], "batches_per_decode_group": key[2], "encoder_engines": key[3], "decode_engines": key[4]}}
+    model._close_pool()
+    return out
+
+
+def prompt75_run(eng, dims, opts, dev, batch, args):
+    """The reference always passes initial_prompt (transcribe.py:40,111), about 70 tokens, which whisperx feeds as
+    <|startofprev|> prompt <|startoftranscript|> <|zh|> <|transcribe|> <|notimestamps|>: 75 forced positions before the
+    first sampled token.  The headline's arrangement with such a prompt (prefilled in one pass per group)."""
+    import torch
+    from manual_whisper_amd import synth
+    from manual_whisper_amd.decode_options import DecodeOptions
+    from manual_whisper_amd.scheduler import GroupedPool
+    rng = np.random.default_rng(0)
+    prompt = tuple(int(t) for t in rng.integers(0, 50000, size=75 - len(opts.prompt))) + tuple(opts.prompt)
+    o75 = DecodeOptions(prompt, opts.eot, opts.suppress, opts.begin_suppress, opts.max_new)
+    pool = GroupedPool(eng, batch, args.group, args.encoders, args.decoders)
+    pool.set_decode_options(o75)
+    pcms = [synth.make_pcm_torch(batch, seed=7000 + i, device=dev) for i in range(2)]
+    torch.cuda.synchronize()
+    pool.map([pcms[0]] * (args.group * args.decoders))
+    torch.cuda.synchronize()
+    steps = 14
+    t0 = time.perf_counter()
+    pool.map([pcms[i % 2] for i in range(steps)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for e in reversed(pool.engines):
+        if e is not eng:
+            e.close()
+    eng.set_decode_options(opts)
+    torch.cuda.empty_cache()
+    return {"workload": f"as config.workload with a forced prompt of 75 ids per chunk (the reference's initial_prompt + task tokens), {steps} steps timed",
+            "value": round(steps * batch * 30.0 / dt, 2), "unit": "audio-seconds/second", "ms_per_step": round(dt / steps * 1e3, 3)}
+
+
+def beam5_run(dims, opts, dev, local_rank, weights="f16", kv="f16", n_rec=25, engines=2, passes=3):
+    """whisperx decodes with a beam of 5 unless told otherwise, and the reference overrides only initial_prompt
+    (transcribe.py:111): the same chunks through mw_decode_beam, `n_rec` recordings (x 5 hypotheses) per pass."""
+    import torch
+    from manual_whisper_amd import synth
+    from manual_whisper_amd.engine import Engine
+    from manual_whisper_amd.scheduler import EnginePool
+    beam = 5
+    eng = Engine(dims, device=local_rank, max_batch=n_rec * beam, weight_format=weights, kv_format=kv)
+    eng.load_weights(synth.make_weights_torch(dims, seed=1234, device=dev))
+    eng.set_decode_options(opts)
+    pool = EnginePool(eng, engines, beam_size=beam)
+    pcms = [synth.make_pcm_torch(n_rec, seed=6000 + i, device=dev) for i in range(2)]
+    torch.cuda.synchronize()
+    pool.map([pcms[i % 2] for i in range(engines)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pool.map([pcms[i % 2] for i in range(engines * passes)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pool.close()
+    torch.cuda.empty_cache()
+    return {"workload": f"beam search, beam 5, patience 1, {n_rec} chunks x 5 hypotheses per pass, {engines} engines in flight, {engines * passes} passes timed, "
+                        f"{len(opts.prompt)} prompt + {opts.max_new} sampled tokens (EOT suppressed)",
+            "value": round(engines * passes * n_rec * 30.0 / dt, 2), "unit": "audio-seconds/second", "ms_per_pass": round(dt / (engines * passes) * 1e3, 2)}
+
+
+def e2e_run(local_rank, minutes=60, tokens=128):
+    """The reference's call shape end to end (transcribe.py:107-135): load_model with its VAD_OPTIONS, model.transcribe on
+    a host buffer holding a 60-minute recording (speech windows -> chunks -> passes -> segments), then forced alignment of
+    the segments.  Synthetic weights, white noise, no vocabulary: the aligned text is random characters of the alignment
+    model's dictionary, the times are the segments'."""
+    import manual_whisper_amd as mw
+    from manual_whisper_amd import alignment, localckpt
+    rng = np.random.default_rng(0)
+    audio = (0.1 * rng.standard_normal(minutes * 60 * 16000)).astype(np.float32)
+    t = time.perf_counter()
+    model = mw.load_model("synthetic:large-v3", "cuda", device_index=local_rank, compute_type="float16", language="zh",
+                          asr_options={"max_new_tokens": tokens}, vad_options={"vad_onset": 0.5, "vad_offset": 0.363})
+    t_load = time.perf_counter() - t
+    model.transcribe(audio[: 5 * 60 * 16000], batch_size=BATCH)        # first call: engines and graphs (the reference's run pays it too; reported apart)
+    t = time.perf_counter()
+    result = model.transcribe(audio, batch_size=BATCH, language="zh")
+    t_tr = time.perf_counter() - t
+    model.close()
+    segs = result["segments"]
+    cfg = localckpt.wav2vec2_config("w2v-large")
+    al = alignment.Aligner(cfg, device=local_rank, max_seconds=30)
+    al.load_weights(localckpt.make_wav2vec2_weights_np(cfg, 77))
+    vocab = localckpt.synthetic_ctc_vocab(cfg["vocab_size"])
+    chars = [c for c in vocab if len(c) == 1 and ord(c) >= 0x4E00]
+    meta = {"language": "zh", "dictionary": vocab, "type": "huggingface"}
+    for s_ in segs:
+        s_["text"] = "".join(rng.choice(chars, max(1, int(5 * (s_["end"] - s_["start"])))))     # ~5 characters per second
+    alignment.align(segs[:8 * al.n_streams], al, meta, audio, "cuda")
+    t = time.perf_counter()
+    res = alignment.align(segs, al, meta, audio, "cuda")
+    t_al = time.perf_counter() - t
+    al.close()
+    dur = minutes * 60.0
+    return {"workload": f"load_model('synthetic:large-v3', vad_options of the reference) -> model.transcribe({minutes} min of white noise in host memory, "
+                        f"batch_size={BATCH}) -> align(segments), {tokens} sampled tokens per window (no end-of-text in synthetic weights)",
+            "windows": len(segs), "load_model_s": round(t_load, 2), "transcribe_s": round(t_tr, 3), "align_s": round(t_al, 3),
+            "transcribe_audio_s_per_s": round(dur / t_tr, 1), "align_audio_s_per_s": round(dur / t_al, 1),
+            "value": round(dur / (t_tr + t_al), 1), "unit": "audio-seconds of recording/second (transcribe + align)", "words": len(res["word_segments"]),
+            "note": "white noise is all speech to the energy detector, whose cut rule halves it into ~15 s windows, each padded to a 30 s chunk: "
+                    "per second of recording this does twice the chunks of the headline"}
+
+
+def strong_scaling(args, eng, dims, opts, dev, cdev, dist, rank, world, rehearse):
+    """--total-chunks T: BASELINE configs[3] as written.  ONE recording of T chunks (1 h = 120), rank r transcribes the
+    contiguous block parallel.shard_range gives it through Model.transcribe_ids_chunks, one all_gather of (length, ids)
+    rows, the wall time is the slowest rank's.  A step is one transcription of the whole recording."""
+    import torch
+    from manual_whisper_amd import parallel, synth
+    T = args.total_chunks
+    a, b = parallel.shard_range(T, rank, world)
+    # chunk i of the recording is the same whatever N is (row i of one seeded construction); a rank keeps only its block
+    pcm = synth.make_pcm_torch(T, seed=9000, device=dev)[a:b].contiguous()
+    torch.cuda.synchronize()
+    model = make_model(eng, dims, opts, group=args.group, n_encoders=args.encoders, n_decoders=args.decoders)
+    per = (T + world - 1) // world
+
+    def one_pass():
+        ids = model.transcribe_ids_chunks(pcm, args.batch) if b > a else []
+        rows = torch.from_numpy(parallel.pack_rows(ids, opts.max_new, per)).to(cdev)
+        if world > 1:
+            gathered = torch.empty((world * per, rows.shape[1]), dtype=torch.int32, device=cdev)
+            dist.all_gather_into_tensor(gathered, rows)
+            rows = gathered
+        return rows
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):            # the first pass builds the engines and captures the graphs
+        one_pass()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows = one_pass()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    n_rows = int((rows[:, 0] >= 0).sum().item())
+    key = model._pool_key
+    model._close_pool()
+    if rank != 0:
+        return
+    assert n_rows == T, (n_rows, T)
+    audio_s = T * 30.0 * args.steps
+    print(json.dumps({
+        "metric": "audio-seconds transcribed/sec (RTF) large-v3 fp16, 30 s chunks, 1/2/4/8 GPU",
+        "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/second", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f16" if args.weights == "f16" else "fp8 weights (e4m3) / f16 activations",
+        "data": "synthetic" if not rehearse else "synthetic; REHEARSAL: all ranks on one GPU, gloo exchange, not a measurement",
+        "rtf": round(elapsed / audio_s, 6),
+        "config": {"workload": f"whisper-{args.model}, ONE recording of {T} chunks of 30 s ({T * 30 / 3600:.2f} h) per step, contiguous blocks of "
+                               f"{per} chunks per rank, batch_size {args.batch}, greedy, {len(opts.prompt)} prompt + {opts.max_new} sampled tokens per chunk "
+                               "(EOT suppressed), one all_gather of ids per step; a step runs from an idle GPU to the gathered ids",
+                   "chunks_per_rank": per, "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
+                   "arrangement_per_rank": {"batch": key[1], "batches_per_decode_group": key[2], "encoder_engines": key[3], "decode_engines": key[4]},
+                   "parallelism": f"dp{world} over the chunks of one recording, one all_gather of ids at the end"},
+        "roofline": None, "cpu_baseline": None,
+        "note": "strong-scaling side mode (--total-chunks); the default command is the weak-scaling headline and carries roofline and cpu_baseline"}), flush=True)
 
 
 def free_port() -> int:
@@ -283,9 +492,20 @@ def main(argv=None):
     ap.add_argument("--no-fp8-b32", action="store_true", help="N=1 only: skip the configs[4] side measurement (fp8 weights, batch 32)")
     ap.add_argument("--no-align", action="store_true", help="N=1 only: skip the forced-alignment side measurement")
     ap.add_argument("--batch", type=int, default=16, help="30 s chunks per step per GPU (configs[4] uses 32)")
+    ap.add_argument("--total-chunks", type=int, default=0,
+                    help="strong scaling (BASELINE configs[3] as written): ONE recording of this many 30 s chunks (1 h = 120) per step, split "
+                         "over the ranks in contiguous blocks; 0 = the weak-scaling headline (--batch chunks per step per GPU)")
+    ap.add_argument("--no-rank-share", action="store_true", help="N=1 only: skip the per-rank shares of a 1 h recording (15 / 30 / 60 / 120 chunks)")
+    ap.add_argument("--no-prompt75", action="store_true", help="N=1 only: skip the side measurement with a 75-id forced prompt")
+    ap.add_argument("--no-beam5", action="store_true", help="N=1 only: skip the beam-5 side measurement")
+    ap.add_argument("--no-e2e", action="store_true", help="N=1 only: skip the end-to-end call-surface measurement (VAD windows, transcribe, align)")
+    ap.add_argument("--only-main", action="store_true", help="skip every side measurement and the CPU baseline")
     ap.add_argument("--tokens", type=int, default=NEW_TOKENS, help="sampled tokens per chunk (the metric is quoted at 128; 32 and 224 are the side cases)")
     args = ap.parse_args(argv)
     NEW_TOKENS = args.tokens
+    if args.only_main:
+        args.no_cpu_baseline = args.no_ungrouped = args.no_fp8_b32 = args.no_align = True
+        args.no_rank_share = args.no_prompt75 = args.no_beam5 = args.no_e2e = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, argv))
 
@@ -322,6 +542,15 @@ def main(argv=None):
     eng = Engine(dims, device=local_rank, max_batch=batch, weight_format=args.weights, kv_format=args.kv)
     eng.load_weights(weights)
     eng.set_decode_options(opts)
+    if args.total_chunks > 0:
+        del weights
+        torch.cuda.empty_cache()
+        strong_scaling(args, eng, dims, opts, dev, cdev, dist, rank, world, rehearse)
+        eng.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     grouped = args.group > 1
     pool = GroupedPool(eng, batch, args.group, args.encoders, args.decoders) if grouped else EnginePool(eng, args.engines)
     if grouped:
@@ -417,7 +646,7 @@ def main(argv=None):
                                    f"hipGraph decode step, " + (f"every step's log-mel / encoder / cross-K/V on its own 16 chunks ({args.encoders} encoder engines), "
                                                                 f"greedy loop over the sequences of up to {args.group} steps at once ({args.decoders} decode engines), "
                                                                 if grouped else f"{args.engines} engines (steps) in flight per GPU, ") +
-                                   f"GPU_MAX_HW_QUEUES={os.environ['GPU_MAX_HW_QUEUES']} (set by bench.py; the library's own default is HIP's 4)",
+                                   f"GPU_MAX_HW_QUEUES={os.environ['GPU_MAX_HW_QUEUES']} (what the package sets for every caller when it is imported)",
                        "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "parallelism": f"dp{world} over chunks, one all_gather of ids at the end"},
             "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items() if k != "decode_steps"},
@@ -480,13 +709,33 @@ def main(argv=None):
             out["fp8_b32"] = fp8_b32_run(dims, opts, dev, local_rank)
         if world == 1 and not args.no_align and args.model == MODEL:
             out["align"] = align_side_run(local_rank)
+        if world == 1 and grouped and not args.no_rank_share and args.model == MODEL and args.weights == "f16":
+            out["rank_share"] = rank_share_run(eng, dims, opts, dev, batch)
+        if world == 1 and grouped and not args.no_prompt75 and args.model == MODEL:
+            out["prompt75"] = prompt75_run(eng, dims, opts, dev, batch, args)
+        if world == 1 and not args.no_beam5 and args.model == MODEL and args.weights == "f16":
+            out["beam5"] = beam5_run(dims, opts, dev, local_rank)
+        if world == 1 and not args.no_e2e and args.model == MODEL and args.weights == "f16":
+            out["e2e"] = e2e_run(local_rank, tokens=NEW_TOKENS)
         if weights_np is not None:
             def gpu_ids(pcm, n_new):
                 o = synthetic_options(dims, max_new=n_new, suppress_eot=True)
                 eng.set_decode_options(o)
                 ids, _ = eng.transcribe_batch(pcm)
                 return ids
-            out["cpu_baseline"] = cpu_baseline(dims, weights_np, opts, gpu_ids, args.weights, args.kv)
+            def gpu_ids_grouped(pcm, n_new):
+                o = synthetic_options(dims, max_new=n_new, suppress_eot=True)
+                gp = GroupedPool(eng, batch, args.group, 1, 1)
+                gp.set_decode_options(o)
+                first = torch.cat([torch.from_numpy(pcm).to(dev), synth.make_pcm_torch(batch - 1, seed=8100, device=dev)])
+                rest = synth.make_pcm_torch(batch, seed=8101, device=dev)
+                torch.cuda.synchronize()
+                res = gp.map([first] + [rest] * (args.group - 1))
+                for e in reversed(gp.engines):
+                    if e is not eng:
+                        e.close()
+                return res[0][0][:1]
+            out["cpu_baseline"] = cpu_baseline(dims, weights_np, opts, gpu_ids, args.weights, args.kv, gpu_ids_grouped if grouped else None)
         print(json.dumps(out), flush=True)
     pool.close()
     if world > 1:

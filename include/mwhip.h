@@ -166,6 +166,14 @@ int mw_encode_into(mw_ctx* ctx, const float* pcm, int batch, mw_ctx* dst, int sl
  * have returned): mw_decode_greedy / mw_decode_beam / mw_decode_forced of `batch` sequences may follow. */
 int mw_set_encoded(mw_ctx* ctx, int batch);
 
+/* Test hook: what the cross-attention K/V projection left in the cache for one sequence of one decoder layer, as
+ * float32 [n_heads][n_audio_ctx][64] each (the decoder reads exactly these rows at every step; an e4m3 cache is
+ * returned as code * row scale).  `sequence` is among those encoded last (mw_encode, or mw_encode_into +
+ * mw_set_encoded).  No counterpart in the reference's call surface: the tensors are those of the cross-attention
+ * branch of Hugging Face's WhisperAttention (modeling_whisper.py:321-335: K = Wk enc, no bias; V = Wv enc + bv; head
+ * split), which whisperx's backend keeps internal behind model.transcribe (reference transcribe.py:123). */
+int mw_read_cross_kv(mw_ctx* ctx, int layer, int sequence, float* k_out, float* v_out);
+
 /* Stage 3: greedy decoding of the chunks encoded last.
  * out_ids: int32 [batch][max_new] (padded with eot); out_len: int32 [batch] = tokens
  * before eot.  logits_out (optional): float32 [max_new][batch][vocab], the raw
@@ -198,7 +206,8 @@ int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience, int32_t* 
  * ids.  temperature 0: the arg-max (greedy decoding with its log-probabilities).  A sample's score is the sum
  * of log-softmax(logits) of its tokens, end-of-text included; the recording's result is the sample with the highest
  * score per token.  active (optional, uint8 [n_audio], host memory): recordings with 0 are not decoded (length 0, no
- * cross-attention reads), so that a fallback pass pays only for the windows that failed.
+ * cross-attention reads: a fallback pass spares the K/V stream of the windows that passed; their rows still ride
+ * through the other launches of every step).
  * out_ids int32 [n_audio][max_new] padded with eot; out_len int32 [n_audio]; out_avg_logprob float32 [n_audio] or
  * NULL (score / (len + 1)).  Optional (NULL to skip): every sample, smp_ids int32 [n_audio][best_of][max_new],
  * smp_len int32 [n_audio][best_of], smp_sum_logprob float32 [n_audio][best_of]; logits_out float32
@@ -282,7 +291,9 @@ typedef struct {
     int32_t pos_kernel;         /* 128: taps of the positional convolution                          */
     int32_t pos_groups;         /* 16                                                               */
     int32_t vocab;              /* rows of lm_head                                                  */
-    int32_t max_samples;        /* longest waveform one mw_align_emissions call takes (<= 960000)   */
+    int32_t max_samples;        /* samples one call takes through the model: the longest waveform of
+                                 * mw_align_emissions / mw_align_segment, or n_segments x the longest
+                                 * segment of a mw_align_segments pack (<= 9600000)                   */
 } mw_align_desc;
 
 /* Frames the feature extractor makes of n_samples samples (valid convolutions). */
@@ -324,6 +335,19 @@ int mw_align_path(const float* emission, int32_t n_frames, int32_t vocab, const 
  * for mw_align_emissions; token_index and score need room for mw_align_frames(desc, n_samples) entries. */
 int mw_align_segment(mw_aligner* a, const float* pcm, int64_t n_samples, const int32_t* tokens, int32_t n_tokens,
                      int32_t blank_id, int32_t* token_index, float* score, int32_t* n_frames);
+
+/* mw_align_segment for a pack of 1..32 segments in ONE pass of the acoustic model (whisperx.align walks the segments
+ * one at a time, reference transcribe.py:131; segments are independent, and one segment is a fraction of what fills
+ * the GPU).  Every segment takes a slice as long as the longest one (zero-padded behind), so n_segments x the longest
+ * n_samples must fit max_samples; the convolutions, LayerNorms and matrix products run once over all slices, the
+ * positional convolution and the attention use each segment's own frames, so a segment's result does not depend on
+ * what shares its pack.  pcm[b]: segment b's samples (host or device); tokens: the segments' token lists back to
+ * back, n_tokens[b] of them for segment b; token_index, score: the segments' frames back to back (room for the sum of
+ * mw_align_frames(desc, n_samples[b])); n_frames[b] frames of segment b; status[b]: MW_OK, or MW_ERR_STATE when
+ * segment b has no path (fewer frames than tokens; its stretch of token_index / score is then undefined). */
+int mw_align_segments(mw_aligner* a, int32_t n_segments, const float* const* pcm, const int64_t* n_samples,
+                      const int32_t* tokens, const int32_t* n_tokens, int32_t blank_id, int32_t* token_index, float* score,
+                      int32_t* n_frames, int32_t* status);
 
 #ifdef __cplusplus
 }

@@ -14,10 +14,10 @@ LIB_PATH = os.environ.get("MW_LIB_PATH") or os.path.join(_HERE, "libmwhip.so")  
 # every symbol include/mwhip.h declares
 SYMBOLS = (
     "mw_create", "mw_fork", "mw_fork_sized", "mw_set_weight", "mw_finalize", "mw_set_decode_opts", "mw_destroy", "mw_last_error",
-    "mw_logmel", "mw_logmel_noalloc", "mw_encode", "mw_encode_into", "mw_set_encoded", "mw_decode_greedy", "mw_decode_beam", "mw_decode_sample", "mw_sample_uniform", "mw_decode_forced", "mw_transcribe_batch",
+    "mw_logmel", "mw_logmel_noalloc", "mw_encode", "mw_encode_into", "mw_set_encoded", "mw_read_cross_kv", "mw_decode_greedy", "mw_decode_beam", "mw_decode_sample", "mw_sample_uniform", "mw_decode_forced", "mw_transcribe_batch",
     "mw_frame_energy_db", "mw_stage_ms", "mw_profile_cross_attention", "mw_profile_decode_gemvs", "mw_set_option", "mw_synchronize",
     "mw_align_frames", "mw_align_create", "mw_align_destroy", "mw_align_last_error", "mw_align_set_weight", "mw_align_finalize",
-    "mw_align_emissions", "mw_align_fork", "mw_align_path", "mw_align_segment",
+    "mw_align_emissions", "mw_align_fork", "mw_align_path", "mw_align_segment", "mw_align_segments",
 )
 
 
@@ -141,6 +141,7 @@ def load() -> C.CDLL:
     lib.mw_fork_sized.argtypes = [vp, C.c_int, C.POINTER(vp)]
     lib.mw_encode_into.argtypes = [vp, f32p, C.c_int, vp, C.c_int]
     lib.mw_set_encoded.argtypes = [vp, C.c_int]
+    lib.mw_read_cross_kv.argtypes = [vp, C.c_int, C.c_int, f32p, f32p]
     lib.mw_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int, C.c_int]
     lib.mw_finalize.argtypes = [vp]
     lib.mw_set_decode_opts.argtypes = [vp, C.POINTER(DecodeOpts)]
@@ -176,6 +177,7 @@ def load() -> C.CDLL:
     lib.mw_align_emissions.argtypes = [vp, f32p, C.c_int64, f32p, C.POINTER(C.c_int32)]
     lib.mw_align_fork.argtypes = [vp, C.POINTER(vp)]
     lib.mw_align_segment.argtypes = [vp, f32p, C.c_int64, vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
+    lib.mw_align_segments.argtypes = [vp, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp]
     lib.mw_align_path.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp]
     for name in SYMBOLS:
         if name not in ("mw_destroy", "mw_last_error", "mw_align_destroy", "mw_align_last_error", "mw_align_frames", "mw_sample_uniform"):

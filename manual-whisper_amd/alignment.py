@@ -50,7 +50,7 @@ class Aligner:
     copy of the workspaces with its own stream (``mw_align_fork``; the weights are shared).  One segment is about
     1500 frames, a fraction of what fills the GPU."""
 
-    def __init__(self, cfg: dict, device: int = 0, max_seconds: int = MAX_ALIGN_SECONDS, n_streams: int = 8):
+    def __init__(self, cfg: dict, device: int = 0, max_seconds: int = MAX_ALIGN_SECONDS, n_streams: int = 3, pack_seconds: int = 240):
         if cfg.get("feat_extract_norm", "group") != "layer" or not cfg.get("do_stable_layer_norm", False) or not cfg.get("conv_bias", False):
             raise EngineError("only the wav2vec2 variant with a layer-norm feature extractor, convolution biases and stable "
                               "layer norm (wav2vec2-large-xlsr-53 and its fine-tunes) is built")
@@ -67,7 +67,10 @@ class Aligner:
         d.ffn_dim = cfg["intermediate_size"]
         d.pos_kernel, d.pos_groups = cfg["num_conv_pos_embeddings"], cfg["num_conv_pos_embedding_groups"]
         d.vocab = cfg["vocab_size"]
-        d.max_samples = int(max_seconds) * SAMPLE_RATE
+        # One pass of the model takes a PACK of segments (mw_align_segments): `pack_seconds` of audio as slices of the
+        # pack's longest segment; a single segment may be up to `max_seconds` long.
+        self.max_segment_samples = int(max_seconds) * SAMPLE_RATE
+        d.max_samples = max(int(max_seconds), int(pack_seconds)) * SAMPLE_RATE
         self.desc = d
         h = C.c_void_p()
         rc = self._lib.mw_align_create(C.byref(d), device, C.byref(h))
@@ -110,8 +113,13 @@ class Aligner:
     def n_frames(self, n_samples: int) -> int:
         return int(self._lib.mw_align_frames(C.byref(self.desc), int(n_samples)))
 
+    def _check_length(self, n: int, what: str):
+        if n > self.max_segment_samples:
+            raise EngineError(f"{what}: more than max_samples samples ({self.max_segment_samples}: max_seconds of this aligner)")
+
     def emissions(self, wave) -> np.ndarray:
         wave = np.ascontiguousarray(wave, dtype=np.float32).reshape(-1)
+        self._check_length(len(wave), "mw_align_emissions")
         out = np.empty((max(self.n_frames(len(wave)), 1), self.cfg["vocab_size"]), np.float32)
         n = C.c_int32(0)
         h = self._free.get() if self._ready else self._h        # before load_weights the call itself reports the state
@@ -134,6 +142,7 @@ class Aligner:
             em = self.emissions(wave)
             return ctc_path(em, tokens, blank_id), em.shape[0]
         wave = np.ascontiguousarray(wave, dtype=np.float32).reshape(-1)
+        self._check_length(len(wave), "mw_align_segment")
         tok = np.ascontiguousarray(tokens, dtype=np.int32)
         T = max(self.n_frames(len(wave)), 1)
         idx, sc = np.empty(T, np.int32), np.empty(T, np.float32)
@@ -152,6 +161,52 @@ class Aligner:
         if rc == -2:
             return None, n.value
         return [Point(int(j), t, float(p)) for t, (j, p) in enumerate(zip(idx[: n.value], sc[: n.value]))], n.value
+
+    MAX_PACK_SEGMENTS = 32
+
+    def pack_fits(self, sample_counts: Sequence[int], token_counts: Sequence[int]) -> bool:
+        """Whether segments of these lengths (samples) and token counts go through ``segments_path`` as one pack."""
+        n = len(sample_counts)
+        if n < 1 or n > self.MAX_PACK_SEGMENTS or max(token_counts) > self.MAX_SEGMENT_TOKENS:
+            return False
+        if n * max(sample_counts) > self.desc.max_samples or (n == 1 and sample_counts[0] > self.max_segment_samples):
+            return False
+        gather = sum(max(self.n_frames(c), 1) * (t + 1) for c, t in zip(sample_counts, token_counts))
+        return gather <= (self.n_frames(self.desc.max_samples) + 64) * (self.MAX_SEGMENT_TOKENS + 1)
+
+    def segments_path(self, waves: Sequence[np.ndarray], tokens: Sequence[Sequence[int]], blank_id: int = 0):
+        """``segment_path`` for a pack of segments in one pass of the model (``mw_align_segments``): -> [(path or None,
+        frames)] in the order given.  The caller checks ``pack_fits`` first."""
+        n = len(waves)
+        waves = [np.ascontiguousarray(w, dtype=np.float32).reshape(-1) for w in waves]
+        for w in waves:
+            self._check_length(len(w), "mw_align_segments")
+        toks = [np.ascontiguousarray(t, dtype=np.int32) for t in tokens]
+        frames = [max(self.n_frames(len(w)), 1) for w in waves]
+        ptrs = (C.c_void_p * n)(*[w.ctypes.data for w in waves])
+        counts = (C.c_int64 * n)(*[len(w) for w in waves])
+        tok_all = np.ascontiguousarray(np.concatenate(toks), dtype=np.int32)
+        n_tok = (C.c_int32 * n)(*[len(t) for t in toks])
+        idx, sc = np.empty(sum(frames), np.int32), np.empty(sum(frames), np.float32)
+        got, status = (C.c_int32 * n)(), (C.c_int32 * n)()
+        h = self._free.get() if self._ready else self._h
+        try:
+            rc = self._lib.mw_align_segments(h, n, ptrs, counts, tok_all.ctypes.data, n_tok, int(blank_id), idx.ctypes.data, sc.ctypes.data,
+                                             got, status)
+            if rc != 0:
+                raise EngineError(f"mw_align_segments failed ({rc}): {self._lib.mw_align_last_error(h).decode()}")
+        finally:
+            if self._ready:
+                self._free.put(h)
+        out, at = [], 0
+        for b in range(n):
+            T = got[b]
+            if status[b] != 0:
+                out.append((None, T))
+            else:
+                out.append(([Point(int(j), t, float(p)) for t, (j, p) in enumerate(zip(idx[at: at + T], sc[at: at + T]))], T))
+            at += T
+        return out
 
     def close(self):
         for h in getattr(self, "_forks", []):                  # forks borrow the weights: they go first
@@ -358,8 +413,8 @@ def align(transcript: Sequence[dict], model: Aligner, align_model_metadata: dict
         if ch in ("[pad]", "<pad>"):
             blank_id = code
 
-    def align_one(sdx_segment):
-        sdx, segment = sdx_segment
+    def prepare(sdx, segment):
+        """-> ("done", [segment as it is]) for a segment nothing can be aligned in, else ("todo", what `finish` needs)."""
         prep = _prepare(segment, dictionary, lang)
         t1, t2, text = segment["start"], segment["end"], segment["text"]
         fallback = {"start": t1, "end": t2, "text": text, "words": [], "chars": [] if return_char_alignments else None}
@@ -367,20 +422,38 @@ def align(transcript: Sequence[dict], model: Aligner, align_model_metadata: dict
             print(f"Progress: {(sdx + 1) / max(len(transcript), 1) * (50 if combined_progress else 100) + (50 if combined_progress else 0):.2f}%...")
         if not prep["clean_char"]:
             print(f'Failed to align segment ("{text}"): no characters in this segment found in model dictionary, resorting to original...')
-            return [fallback]
+            return "done", [fallback]
         if t1 >= max_duration:
             print(f'Failed to align segment ("{text}"): original start time longer than audio duration, skipping...')
-            return [fallback]
+            return "done", [fallback]
         text_clean = "".join(prep["clean_char"])
         tokens = [dictionary.get(c, -1) for c in text_clean]
         wave = audio[int(t1 * SAMPLE_RATE): int(t2 * SAMPLE_RATE)]
         if len(wave) < MIN_SAMPLES:
             wave = np.pad(wave, (0, MIN_SAMPLES - len(wave)))
-        if hasattr(model, "segment_path"):
-            path, n_frames = model.segment_path(wave, tokens, blank_id)
-        else:                                                   # any object with emissions(wave) -> [frames][vocab]
-            emission = model.emissions(wave)
-            path, n_frames = ctc_path(emission, tokens, blank_id), emission.shape[0]
+        return "todo", {"prep": prep, "fallback": fallback, "text_clean": text_clean, "tokens": tokens, "wave": wave, "segment": segment}
+
+    def run_one(todo):
+        """The acoustic model and the search for one segment -> (path or None, frames); an engine failure -> None."""
+        wave, tokens, text = todo["wave"], todo["tokens"], todo["segment"]["text"]
+        try:
+            if hasattr(model, "segment_path"):
+                return model.segment_path(wave, tokens, blank_id)
+            emission = model.emissions(wave)                    # any object with emissions(wave) -> [frames][vocab]
+            return ctc_path(emission, tokens, blank_id), emission.shape[0]
+        except EngineError as e:
+            # one segment the model cannot take (longer than the aligner's max_seconds, for one) must not lose the
+            # others: like every other per-segment failure it keeps its original times
+            print(f'Failed to align segment ("{text}"): {e}, resorting to original...')
+            return None
+
+    def finish(todo, result):
+        prep, fallback, text_clean = todo["prep"], todo["fallback"], todo["text_clean"]
+        segment = todo["segment"]
+        t1, t2, text = segment["start"], segment["end"], segment["text"]
+        if result is None:
+            return [fallback]
+        path, n_frames = result
         if path is None:
             print(f'Failed to align segment ("{text}"): backtrack failed, resorting to original...')
             return [fallback]
@@ -446,14 +519,48 @@ def align(transcript: Sequence[dict], model: Aligner, align_model_metadata: dict
                 merged[key] = dict(s, start=a, end=b)
         return [merged[k] for k in sorted(merged)]
 
-    # segments are independent: several in flight keep the GPU busy (the model runs up to n_streams at once) and
-    # overlap one segment's search on the host with another's acoustic model; results keep the segments' order
+    # Segments are independent.  With the GPU model they go through it in PACKS (one pass over up to 32 segments of
+    # like length, Aligner.segments_path), several packs in flight (the model runs n_streams at once, and one pack's
+    # search on the host overlaps another's acoustic model); results keep the segments' order.
+    prepared = [prepare(sdx, seg) for sdx, seg in enumerate(transcript)]
+    parts: List[Optional[list]] = [p[1] if p[0] == "done" else None for p in prepared]
+    todo = [(i, p[1]) for i, p in enumerate(prepared) if p[0] == "todo"]
     workers = max(1, int(getattr(model, "n_streams", 1)))
-    if workers > 1 and len(transcript) > 1:
-        with ThreadPoolExecutor(max_workers=workers) as pool:
-            parts = list(pool.map(align_one, enumerate(transcript)))
+    if hasattr(model, "segments_path") and hasattr(model, "pack_fits"):
+        packs: List[List[Tuple[int, dict]]] = []
+        for i, t in sorted(todo, key=lambda it: -len(it[1]["wave"])):           # longest first: a pack's slices are its first segment's length
+            cur = packs[-1] if packs else None
+            if cur is not None and model.pack_fits([len(x[1]["wave"]) for x in cur] + [len(t["wave"])],
+                                                   [len(x[1]["tokens"]) for x in cur] + [len(t["tokens"])]):
+                cur.append((i, t))
+            else:
+                packs.append([(i, t)])
+
+        def run_pack(pack):
+            if len(pack) == 1 and not model.pack_fits([len(pack[0][1]["wave"])], [len(pack[0][1]["tokens"])]):
+                return [run_one(pack[0][1])]                    # too long or too many characters for a pack: the single-segment call decides
+            try:
+                return model.segments_path([t["wave"] for _, t in pack], [t["tokens"] for _, t in pack], blank_id)
+            except EngineError as e:
+                print(f"Failed to align a pack of {len(pack)} segments ({e}): aligning them one at a time...")
+                return [run_one(t) for _, t in pack]
+
+        if workers > 1 and len(packs) > 1:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                results = list(pool.map(run_pack, packs))
+        else:
+            results = [run_pack(p) for p in packs]
+        for pack, res in zip(packs, results):
+            for (i, t), r in zip(pack, res):
+                parts[i] = finish(t, r)
     else:
-        parts = [align_one(x) for x in enumerate(transcript)]
+        if workers > 1 and len(todo) > 1:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                results = list(pool.map(lambda it: run_one(it[1]), todo))
+        else:
+            results = [run_one(t) for _, t in todo]
+        for (i, t), r in zip(todo, results):
+            parts[i] = finish(t, r)
     aligned_segments: List[dict] = [seg for part in parts for seg in part]
 
     word_segments: List[dict] = []

@@ -95,16 +95,19 @@ def transcribe_audio(audio_file, hf_token=None):
     dt = time.time() - t
     say(f"   转写耗时: {dt:.1f}s (实时比: {dt/max(audio_duration, 1e-9):.3f}x, {audio_duration/max(dt, 1e-9):.0f} audio-s/s)")
     model.close()
-    if os.environ.get("MW_ALIGN_MODEL"):
-        if rank == 0:                       # reference transcribe.py:127-135
-            from .alignment import align, load_align_model
-            t = time.time()
-            say("🎯 对齐时间戳...")
-            model_a, metadata = load_align_model(language_code="zh", device=f"cuda:{local_rank}")
-            aligned = align(result["segments"], model_a, metadata, audio, DEVICE, return_char_alignments=False)
-            model_a.close()
-            result = dict(aligned, language=result.get("language", "zh"))
-            say(f"   对齐耗时: {time.time() - t:.1f}s")
+    if os.environ.get("MW_ALIGN_MODEL"):    # reference transcribe.py:127-135
+        # every rank holds the audio and the whole segment list (the ids were gathered on all of them): each aligns its
+        # contiguous block of segments on its own GPU, one gather of the blocks puts the result together
+        from .alignment import align, load_align_model
+        from .parallel import align_sharded
+        t = time.time()
+        say("🎯 对齐时间戳...")
+        model_a, metadata = load_align_model(language_code="zh", device=f"cuda:{local_rank}")
+        aligned = align_sharded(lambda segs: align(segs, model_a, metadata, audio, DEVICE, return_char_alignments=False),
+                                result["segments"])
+        model_a.close()
+        result = dict(aligned, language=result.get("language", "zh"))
+        say(f"   对齐耗时: {time.time() - t:.1f}s")
     else:
         say("⚠️ 未设置 MW_ALIGN_MODEL，跳过时间戳对齐：片段时间为语音活动窗口（≤30 秒）的边界。说话人分离不在本引擎范围内。")
     say("🧹 清理转写文本...")

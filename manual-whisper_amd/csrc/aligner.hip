@@ -36,6 +36,9 @@ struct Layer { Norm ln1, ln2; Lin qkv, out, fc1, fc2; };
 }  // namespace
 
 constexpr int kMaxSegmentTokens = 1024;                    // characters one mw_align_segment call places
+constexpr int kMaxPackSegments = 32;                       // segments one mw_align_segments call takes through the model together
+constexpr int kPackSlackRows = 64;                         // rows of slack per workspace: the frame counts of a pack's equal
+                                                           // slices may add up to a few more than those of one long recording
 
 struct mw_aligner {
     mw_align_desc d{};
@@ -62,8 +65,10 @@ struct mw_aligner {
     f16* pack = nullptr;                                   // [G][T + K][D/G]
     f16 *q = nullptr, *k = nullptr, *vT = nullptr, *att = nullptr, *hid = nullptr;
     float* logits = nullptr;                               // [T][vpad]
-    int32_t* tok_dev = nullptr;                            // [kMaxSegmentTokens]
-    float* gath_dev = nullptr; float* gath_host = nullptr; // [T][1 + n_tokens] gathered log-probabilities (device; pinned host)
+    int32_t* tok_dev = nullptr;                            // [kMaxPackSegments * kMaxSegmentTokens]
+    float* gath_dev = nullptr; float* gath_host = nullptr; // gathered log-probabilities of a pack's segments, back to back (device; pinned host)
+    int32_t* keys_dev = nullptr;                           // [kMaxPackSegments] frames of each segment of the pack in flight
+    size_t gath_floats = 0;
     int max_frames = 0, max_t0 = 0;
 };
 
@@ -104,17 +109,25 @@ static int alloc_align_work(mw_aligner* a) {
     a->max_t0 = (int)frames_after(d, d.max_samples, 1);
     a->max_frames = (int)frames_after(d, d.max_samples, d.n_conv);
     a->vpad = (d.vocab + 63) / 64 * 64;
-    const size_t C = d.conv_dim, D = d.hidden, F = d.ffn_dim, T = a->max_frames, H = d.n_heads;
+    const size_t C = d.conv_dim, D = d.hidden, F = d.ffn_dim, T = a->max_frames + kPackSlackRows, H = d.n_heads;
     const size_t Tpad = (T + 7) / 8 * 8;
     AALLOC(a->pcm, (size_t)d.max_samples);
-    AALLOC(a->h[0], (size_t)a->max_t0 * C); AALLOC(a->h[1], (size_t)frames_after(d, d.max_samples, 2) * C + C);
+    AALLOC(a->h[0], ((size_t)a->max_t0 + kPackSlackRows) * C);
+    AALLOC(a->h[1], ((size_t)frames_after(d, d.max_samples, 2) + kPackSlackRows) * C + C);
     AALLOC(a->x, T * D); AALLOC(a->xn, T * D);
-    AALLOC(a->pack, (size_t)(T + d.pos_kernel) * D);
-    AALLOC(a->q, T * D); AALLOC(a->k, T * D); AALLOC(a->vT, H * 64 * Tpad, true); AALLOC(a->att, T * D); AALLOC(a->hid, T * F);
+    AALLOC(a->pack, (size_t)(T + (size_t)d.pos_kernel * kMaxPackSegments) * D);
+    // att starts at zero: in a packed pass the rows past a segment's own frames are never written, and what they hold
+    // is multiplied by a probability of zero in the attention of the layers that follow: it must be finite
+    AALLOC(a->q, T * D); AALLOC(a->k, T * D); AALLOC(a->vT, H * 64 * (Tpad + 8 * kMaxPackSegments), true); AALLOC(a->att, T * D, true);
+    AALLOC(a->hid, T * F);
     AALLOC(a->logits, T * (size_t)a->vpad);
-    AALLOC(a->tok_dev, (size_t)kMaxSegmentTokens);
-    AALLOC(a->gath_dev, T * (size_t)(kMaxSegmentTokens + 1));
-    if (hipHostMalloc(reinterpret_cast<void**>(&a->gath_host), T * (size_t)(kMaxSegmentTokens + 1) * 4, hipHostMallocDefault) != hipSuccess) {
+    AALLOC(a->tok_dev, (size_t)kMaxPackSegments * kMaxSegmentTokens);
+    AALLOC(a->keys_dev, (size_t)kMaxPackSegments);
+    // gathered columns: one segment may have kMaxSegmentTokens characters over all the frames; a pack of shorter
+    // segments shares the same room (checked per call)
+    a->gath_floats = T * (size_t)(kMaxSegmentTokens + 1);
+    AALLOC(a->gath_dev, a->gath_floats);
+    if (hipHostMalloc(reinterpret_cast<void**>(&a->gath_host), a->gath_floats * 4, hipHostMallocDefault) != hipSuccess) {
         a->err = "hipHostMalloc failed"; return MW_ERR_NOMEM;
     }
     return MW_OK;
@@ -139,7 +152,7 @@ extern "C" int mw_align_create(const mw_align_desc* desc, int device, mw_aligner
     if (d.pos_groups < 1 || d.hidden % d.pos_groups || (d.hidden / d.pos_groups) % 8 || d.pos_kernel < 2 || (d.pos_kernel * (d.hidden / d.pos_groups)) % 64)
         return bad("positional convolution: hidden / groups must be a multiple of 8 and kernel * hidden / groups a multiple of 64");
     if (d.n_layers < 1 || d.vocab < 2) return bad("bad layer count / vocabulary");
-    if (d.max_samples < 400 || d.max_samples > 16000 * 60) return bad("max_samples must be in 400 .. 960000");
+    if (d.max_samples < 400 || d.max_samples > 16000 * 600) return bad("max_samples must be in 400 .. 9600000");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_align_create_error = "mw_align_create: no such HIP device"; return MW_ERR_HIP; }
     mw_aligner* a = new mw_aligner();
@@ -332,85 +345,117 @@ static GemmParams agemm(const f16* A, long lda, const f16* W, long ldw, int M, i
     return p;
 }
 
-// Queue the acoustic model on the aligner's stream: pcm -> log-probabilities in a->logits [T][vpad] (no wait)
-static int run_model(mw_aligner* a, const float* pcm, int64_t n_samples, int* n_frames, const char* who) {
+// Queue the acoustic model on the aligner's stream for a PACK of `n_seg` segments (no wait).  Every segment is laid
+// out as a slice of `L` samples (the longest segment's length, the shorter ones zero-padded behind), so that the
+// feature extractor's seven convolutions, the transformer layers' products and LayerNorms run once over all slices:
+// a frame of the convolution stack only looks forward, so the first frames_after(n_b) frames of slice b are exactly
+// what segment b gives alone and the frames behind them are finite and ignored.  Where frames mix across time the
+// segment's own length is used: the positional convolution runs per segment over its own frames (zero padded as the
+// model pads them), the attention masks the keys past them.  Log-probabilities land in a->logits, slice b at rows
+// b * Tmax .. b * Tmax + frames[b] - 1; *t_stride = Tmax.
+static int run_model(mw_aligner* a, int n_seg, const float* const* pcm, const int64_t* n_samples, int* frames, int* t_stride, const char* who) {
     if (!a->finalized) return afail(a, MW_ERR_STATE, std::string(who) + ": mw_align_finalize has not succeeded yet");
     const mw_align_desc& d = a->d;
-    if (n_samples > d.max_samples) return afail(a, MW_ERR_ARG, std::string(who) + ": more than max_samples samples (" + std::to_string(d.max_samples) + ")");
-    const int T = (int)frames_after(d, n_samples, d.n_conv);
-    if (T < 1) return afail(a, MW_ERR_ARG, std::string(who) + ": the input is shorter than one frame of the feature extractor");
+    if (n_seg < 1 || n_seg > kMaxPackSegments) return afail(a, MW_ERR_ARG, std::string(who) + ": 1.." + std::to_string(kMaxPackSegments) + " segments per call");
+    int64_t L = 0;
+    for (int b = 0; b < n_seg; ++b) {
+        if (!pcm[b]) return afail(a, MW_ERR_ARG, std::string(who) + ": null segment");
+        L = std::max(L, n_samples[b]);
+    }
+    if (L * n_seg > d.max_samples)
+        return afail(a, MW_ERR_ARG, std::string(who) + ": more than max_samples samples (" + std::to_string(d.max_samples) + ")" +
+                                    (n_seg > 1 ? " in " + std::to_string(n_seg) + " slices of the longest segment's length" : ""));
+    const int T = (int)frames_after(d, L, d.n_conv);               // frames of a slice
+    for (int b = 0; b < n_seg; ++b) {
+        frames[b] = (int)frames_after(d, n_samples[b], d.n_conv);
+        if (frames[b] < 1) return afail(a, MW_ERR_ARG, std::string(who) + ": the input is shorter than one frame of the feature extractor");
+    }
+    if ((long)T * n_seg > a->max_frames + kPackSlackRows) return afail(a, MW_ERR_ARG, std::string(who) + ": the pack's frames exceed the workspaces");
     ACHK(hipSetDevice(a->device));
     hipStream_t s = a->stream;
     const int C = d.conv_dim, D = d.hidden, F = d.ffn_dim, H = d.n_heads, G = d.pos_groups, K = d.pos_kernel, W = D / G;
-    ACHK(hipMemcpyAsync(a->pcm, pcm, (size_t)n_samples * 4, hipMemcpyDefault, s));
-    // ---- feature extractor: conv -> LayerNorm over channels -> GELU, seven times
-    int Ti = (int)frames_after(d, n_samples, 1);
-    launch_w2v_conv0(a->pcm, n_samples, a->conv[0].w32, a->conv[0].b, a->conv[0].ln.g, a->conv[0].ln.b, a->h[0], Ti, C, d.conv_kernel[0],
-                     d.conv_stride[0], s);
+    const bool ragged = n_seg > 1;
+    if (ragged) ACHK(hipMemsetAsync(a->pcm, 0, (size_t)L * n_seg * 4, s));
+    for (int b = 0; b < n_seg; ++b) ACHK(hipMemcpyAsync(a->pcm + (size_t)b * L, pcm[b], (size_t)n_samples[b] * 4, hipMemcpyDefault, s));
+    // ---- feature extractor: conv -> LayerNorm over channels -> GELU, seven times; slice b's frames lie Ti apart
+    int Ti = (int)frames_after(d, L, 1);
+    for (int b = 0; b < n_seg; ++b)
+        launch_w2v_conv0(a->pcm + (size_t)b * L, L, a->conv[0].w32, a->conv[0].b, a->conv[0].ln.g, a->conv[0].ln.b, a->h[0] + (size_t)b * Ti * C, Ti, C,
+                         d.conv_kernel[0], d.conv_stride[0], s);
     int cur = 0;
     for (int i = 1; i < d.n_conv; ++i) {
         const ConvL& c = a->conv[i];
         const int To = (Ti - c.k) / c.s + 1;
-        GemmParams p = agemm(a->h[cur], (long)c.s * C, c.w, (long)c.k * C, To, C, c.k * C, c.b);
-        p.C = a->h[cur ^ 1]; p.ldc = C;
+        GemmParams p = agemm(a->h[cur], (long)c.s * C, c.w, (long)c.k * C, To * n_seg, C, c.k * C, c.b);
+        p.a_rows_per_batch = To; p.a_batch_stride = (long)Ti * C;
+        p.C = a->h[cur ^ 1]; p.ldc = C; p.c_rows_per_batch = To; p.c_batch_stride = (long)To * C;
         launch_gemm(p, s);
-        launch_ln16(a->h[cur ^ 1], c.ln.g, c.ln.b, To, C, 1e-5f, 1, s);
+        launch_ln16(a->h[cur ^ 1], c.ln.g, c.ln.b, To * n_seg, C, 1e-5f, 1, s);
         cur ^= 1; Ti = To;
     }
+    const int M = T * n_seg;                                        // Ti == T now: rows of every product below
     // ---- feature projection: LayerNorm, Linear C -> D into the fp32 residual stream
-    launch_ln16(a->h[cur], a->proj_ln.g, a->proj_ln.b, T, C, 1e-5f, 0, s);
-    ACHK(hipMemsetAsync(a->x, 0, (size_t)T * D * 4, s));
+    launch_ln16(a->h[cur], a->proj_ln.g, a->proj_ln.b, M, C, 1e-5f, 0, s);
+    ACHK(hipMemsetAsync(a->x, 0, (size_t)M * D * 4, s));
     {
-        GemmParams p = agemm(a->h[cur], C, a->proj.w, C, T, D, C, a->proj.b);
+        GemmParams p = agemm(a->h[cur], C, a->proj.w, C, M, D, C, a->proj.b);
         p.out_mode = OUT_RESID_F32; p.C = a->x; p.ldc = D;
         launch_gemm(p, s);
     }
-    // ---- x += GELU(grouped positional convolution of x): one GEMM per group over the group-major padded copy
-    launch_w2v_pos_pack(a->x, a->pack, T, D, G, K, s);
-    {   // all groups in one launch: a group alone is a dozen workgroups looping over K = pos_kernel * W
-        GemmParams p = agemm(a->pack, W, a->pos_w, (long)K * W, T, W, K * W, a->pos_b);
-        p.gelu = 1; p.out_mode = OUT_RESID_F32; p.C = a->x; p.ldc = D;
-        p.groups = G; p.a_group_stride = (long)(T + K) * W; p.w_group_stride = (long)W * K * W; p.c_group_stride = W;
+    // ---- x += GELU(grouped positional convolution of x): per segment over its own frames (the model pads a recording
+    // with zeros at both ends), one GEMM per group over the group-major padded copy, all groups in one launch
+    for (int b = 0; b < n_seg; ++b) {
+        float* xb = a->x + (size_t)b * T * D;
+        f16* packb = a->pack + (size_t)b * (T + K) * D;
+        launch_w2v_pos_pack(xb, packb, frames[b], D, G, K, s);
+        GemmParams p = agemm(packb, W, a->pos_w, (long)K * W, frames[b], W, K * W, a->pos_b);
+        p.gelu = 1; p.out_mode = OUT_RESID_F32; p.C = xb; p.ldc = D;
+        p.groups = G; p.a_group_stride = (long)(frames[b] + K) * W; p.w_group_stride = (long)W * K * W; p.c_group_stride = W;
         launch_gemm(p, s);
     }
     // ---- transformer layers (pre-LayerNorm), then the encoder's final LayerNorm
     const int Tpad = (T + 7) / 8 * 8;
     const float qscale = 1.0f / sqrtf((float)kHeadDim);
-    ACHK(hipMemsetAsync(a->vT, 0, (size_t)H * 64 * Tpad * 2, s));
+    ACHK(hipMemsetAsync(a->vT, 0, (size_t)n_seg * H * 64 * Tpad * 2, s));
+    const int* keys_of = nullptr;
+    if (ragged) {
+        ACHK(hipMemcpyAsync(a->keys_dev, frames, (size_t)n_seg * 4, hipMemcpyHostToDevice, s));
+        keys_of = a->keys_dev;
+    }
     for (int li = 0; li < d.n_layers; ++li) {
         const Layer& l = a->layers[li];
-        launch_layernorm(a->x, l.ln1.g, l.ln1.b, a->xn, nullptr, T, D, s);
+        launch_layernorm(a->x, l.ln1.g, l.ln1.b, a->xn, nullptr, M, D, s);
         {
-            GemmParams p = agemm(a->xn, D, l.qkv.w, D, T, 3 * D, D, l.qkv.b);
+            GemmParams p = agemm(a->xn, D, l.qkv.w, D, M, 3 * D, D, l.qkv.b);
             p.scale = qscale; p.scale_ncols = D; p.out_mode = OUT_QKV_SPLIT;
             p.q = a->q; p.k = a->k; p.v = a->vT; p.T = T; p.Tpad = Tpad; p.H = H; p.D = D;
             launch_gemm(p, s);
         }
-        launch_enc_attention(a->q, a->k, a->vT, a->att, 1, H, T, Tpad, s);
-        {   GemmParams p = agemm(a->att, D, l.out.w, D, T, D, D, l.out.b); p.out_mode = OUT_RESID_F32; p.C = a->x; p.ldc = D; launch_gemm(p, s); }
-        launch_layernorm(a->x, l.ln2.g, l.ln2.b, a->xn, nullptr, T, D, s);
-        {   GemmParams p = agemm(a->xn, D, l.fc1.w, D, T, F, D, l.fc1.b); p.gelu = 1; p.C = a->hid; p.ldc = F; launch_gemm(p, s); }
-        {   GemmParams p = agemm(a->hid, F, l.fc2.w, F, T, D, F, l.fc2.b); p.out_mode = OUT_RESID_F32; p.C = a->x; p.ldc = D; launch_gemm(p, s); }
+        launch_enc_attention(a->q, a->k, a->vT, a->att, n_seg, H, T, Tpad, s, keys_of);
+        {   GemmParams p = agemm(a->att, D, l.out.w, D, M, D, D, l.out.b); p.out_mode = OUT_RESID_F32; p.C = a->x; p.ldc = D; launch_gemm(p, s); }
+        launch_layernorm(a->x, l.ln2.g, l.ln2.b, a->xn, nullptr, M, D, s);
+        {   GemmParams p = agemm(a->xn, D, l.fc1.w, D, M, F, D, l.fc1.b); p.gelu = 1; p.C = a->hid; p.ldc = F; launch_gemm(p, s); }
+        {   GemmParams p = agemm(a->hid, F, l.fc2.w, F, M, D, F, l.fc2.b); p.out_mode = OUT_RESID_F32; p.C = a->x; p.ldc = D; launch_gemm(p, s); }
     }
-    launch_layernorm(a->x, a->enc_ln.g, a->enc_ln.b, a->xn, nullptr, T, D, s);
+    launch_layernorm(a->x, a->enc_ln.g, a->enc_ln.b, a->xn, nullptr, M, D, s);
     // ---- CTC head and log-softmax over the vocabulary
-    ACHK(hipMemsetAsync(a->logits, 0, (size_t)T * a->vpad * 4, s));
+    ACHK(hipMemsetAsync(a->logits, 0, (size_t)M * a->vpad * 4, s));
     {
-        GemmParams p = agemm(a->xn, D, a->head.w, D, T, a->vpad, D, a->head.b);
+        GemmParams p = agemm(a->xn, D, a->head.w, D, M, a->vpad, D, a->head.b);
         p.out_mode = OUT_RESID_F32; p.C = a->logits; p.ldc = a->vpad;
         launch_gemm(p, s);
     }
-    launch_log_softmax_rows(a->logits, T, a->vpad, d.vocab, s);
+    launch_log_softmax_rows(a->logits, M, a->vpad, d.vocab, s);
     ACHK(hipGetLastError());
-    *n_frames = T;
+    *t_stride = T;
     return MW_OK;
 }
 
 extern "C" int mw_align_emissions(mw_aligner* a, const float* pcm, int64_t n_samples, float* out, int32_t* n_frames) {
     if (!a) return MW_ERR_ARG;
     if (!pcm || !out || !n_frames) return afail(a, MW_ERR_ARG, "mw_align_emissions: null argument");
-    int T = 0;
-    if (int r = run_model(a, pcm, n_samples, &T, "mw_align_emissions")) return r;
+    int T = 0, stride = 0;
+    if (int r = run_model(a, 1, &pcm, &n_samples, &T, &stride, "mw_align_emissions")) return r;
     const mw_align_desc& d = a->d;
     ACHK(hipMemcpy2DAsync(out, (size_t)d.vocab * 4, a->logits, (size_t)a->vpad * 4, (size_t)d.vocab * 4, T, hipMemcpyDefault, a->stream));
     ACHK(hipStreamSynchronize(a->stream));
@@ -480,32 +525,71 @@ extern "C" int mw_align_path(const float* em, int32_t T, int32_t V, const int32_
     return path_search(b.data(), lp.data(), T, J, J, token_index, score);
 }
 
-// One segment end to end: the acoustic model, then the search, with only the columns the search reads (the blank and
-// the segment's tokens: [T][1 + n_tokens] instead of [T][vocab]) gathered on the GPU and brought to the host through
-// a pinned buffer.
+// Segments end to end: the acoustic model over the whole pack, then each segment's search, with only the columns the
+// search reads (the blank and the segment's tokens: [T][1 + n_tokens] instead of [T][vocab]) gathered on the GPU
+// and brought to the host through a pinned buffer.  tokens: the segments' token lists back to back; token_index and
+// score: the segments' frames back to back (mw_align_frames of each); status[b]: MW_OK, or MW_ERR_STATE when segment
+// b has no path (fewer frames than tokens).
+static int align_pack(mw_aligner* a, int n_seg, const float* const* pcm, const int64_t* n_samples, const int32_t* tokens, const int32_t* n_tokens,
+                      int32_t blank_id, int32_t* token_index, float* score, int32_t* n_frames, int32_t* status, const char* who) {
+    const mw_align_desc& d = a->d;
+    if (blank_id < 0 || blank_id >= d.vocab) return afail(a, MW_ERR_ARG, std::string(who) + ": blank_id outside the vocabulary");
+    if (n_seg < 1 || n_seg > kMaxPackSegments) return afail(a, MW_ERR_ARG, std::string(who) + ": 1.." + std::to_string(kMaxPackSegments) + " segments per call");
+    long n_tok_all = 0;
+    for (int b = 0; b < n_seg; ++b) {
+        if (n_tokens[b] < 1 || n_tokens[b] > kMaxSegmentTokens) return afail(a, MW_ERR_ARG, std::string(who) + ": n_tokens must be in 1.." + std::to_string(kMaxSegmentTokens));
+        for (int j = 0; j < n_tokens[b]; ++j)
+            if (tokens[n_tok_all + j] < -1 || tokens[n_tok_all + j] >= d.vocab) return afail(a, MW_ERR_ARG, std::string(who) + ": token id outside the vocabulary");
+        n_tok_all += n_tokens[b];
+    }
+    int frames[kMaxPackSegments], stride = 0;
+    if (int r = run_model(a, n_seg, pcm, n_samples, frames, &stride, who)) return r;
+    size_t need = 0;
+    for (int b = 0; b < n_seg; ++b) need += (size_t)frames[b] * (n_tokens[b] + 1);
+    if (need > a->gath_floats) return afail(a, MW_ERR_ARG, std::string(who) + ": frames x tokens of the pack exceed the gather buffer");
+    hipStream_t s = a->stream;
+    ACHK(hipMemcpyAsync(a->tok_dev, tokens, (size_t)n_tok_all * 4, hipMemcpyHostToDevice, s));
+    size_t at = 0; long tok_at = 0;
+    for (int b = 0; b < n_seg; ++b) {
+        launch_ctc_gather(a->logits + (size_t)b * stride * a->vpad, frames[b], a->vpad, d.vocab, a->tok_dev + tok_at, n_tokens[b], blank_id,
+                          a->gath_dev + at, s);
+        at += (size_t)frames[b] * (n_tokens[b] + 1); tok_at += n_tokens[b];
+    }
+    ACHK(hipGetLastError());
+    ACHK(hipMemcpyAsync(a->gath_host, a->gath_dev, need * 4, hipMemcpyDeviceToHost, s));
+    ACHK(hipStreamSynchronize(s));
+    at = 0;
+    size_t frame_at = 0;
+    int worst = MW_OK;
+    std::vector<float> blank;
+    for (int b = 0; b < n_seg; ++b) {
+        const int T = frames[b], ld = n_tokens[b] + 1;
+        n_frames[b] = T;
+        // column 0 of the gathered rows is the blank: copy it out so that the search reads two plain arrays
+        blank.resize(T);
+        for (int t = 0; t < T; ++t) blank[t] = a->gath_host[at + (size_t)t * ld];
+        const int r = path_search(blank.data(), a->gath_host + at + 1, T, n_tokens[b], ld, token_index + frame_at, score + frame_at);
+        if (status) status[b] = r;
+        if (r != MW_OK) worst = r;
+        at += (size_t)T * ld; frame_at += T;
+    }
+    if (worst == MW_ERR_STATE) a->err = std::string(who) + ": no path (fewer frames than tokens)";
+    return worst;
+}
+
 extern "C" int mw_align_segment(mw_aligner* a, const float* pcm, int64_t n_samples, const int32_t* tokens, int32_t n_tokens, int32_t blank_id,
                                 int32_t* token_index, float* score, int32_t* n_frames) {
     if (!a) return MW_ERR_ARG;
     if (!pcm || !tokens || !token_index || !score || !n_frames) return afail(a, MW_ERR_ARG, "mw_align_segment: null argument");
-    const mw_align_desc& d = a->d;
-    if (n_tokens < 1 || n_tokens > kMaxSegmentTokens) return afail(a, MW_ERR_ARG, "mw_align_segment: n_tokens must be in 1.." + std::to_string(kMaxSegmentTokens));
-    if (blank_id < 0 || blank_id >= d.vocab) return afail(a, MW_ERR_ARG, "mw_align_segment: blank_id outside the vocabulary");
-    for (int j = 0; j < n_tokens; ++j)
-        if (tokens[j] < -1 || tokens[j] >= d.vocab) return afail(a, MW_ERR_ARG, "mw_align_segment: token id outside the vocabulary");
-    int T = 0;
-    if (int r = run_model(a, pcm, n_samples, &T, "mw_align_segment")) return r;
-    hipStream_t s = a->stream;
-    const int ld = n_tokens + 1;
-    ACHK(hipMemcpyAsync(a->tok_dev, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice, s));
-    launch_ctc_gather(a->logits, T, a->vpad, d.vocab, a->tok_dev, n_tokens, blank_id, a->gath_dev, s);
-    ACHK(hipGetLastError());
-    ACHK(hipMemcpyAsync(a->gath_host, a->gath_dev, (size_t)T * ld * 4, hipMemcpyDeviceToHost, s));
-    ACHK(hipStreamSynchronize(s));
-    *n_frames = T;
-    // column 0 of the gathered rows is the blank: copy it out so that the search reads two plain arrays
-    std::vector<float> blank(T);
-    for (int t = 0; t < T; ++t) blank[t] = a->gath_host[(size_t)t * ld];
-    const int r = path_search(blank.data(), a->gath_host + 1, T, n_tokens, ld, token_index, score);
-    if (r == MW_ERR_STATE) a->err = "mw_align_segment: no path (fewer frames than tokens)";
-    return r;
+    return align_pack(a, 1, &pcm, &n_samples, tokens, &n_tokens, blank_id, token_index, score, n_frames, nullptr, "mw_align_segment");
+}
+
+extern "C" int mw_align_segments(mw_aligner* a, int32_t n_segments, const float* const* pcm, const int64_t* n_samples, const int32_t* tokens,
+                                 const int32_t* n_tokens, int32_t blank_id, int32_t* token_index, float* score, int32_t* n_frames,
+                                 int32_t* status) {
+    if (!a) return MW_ERR_ARG;
+    if (!pcm || !n_samples || !tokens || !n_tokens || !token_index || !score || !n_frames || !status)
+        return afail(a, MW_ERR_ARG, "mw_align_segments: null argument");
+    const int r = align_pack(a, n_segments, pcm, n_samples, tokens, n_tokens, blank_id, token_index, score, n_frames, status, "mw_align_segments");
+    return r == MW_ERR_STATE ? MW_OK : r;          // segments without a path are reported through status[]
 }

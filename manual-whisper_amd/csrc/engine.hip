@@ -29,6 +29,7 @@ constexpr int kMaxBatch = 512;                 // sequences one context holds (a
 constexpr int kMelBlocksPerChunk = (kFrames + 31) / 32;        // 94: the grid of launch_mel_dft
 static __device__ __align__(256) float scratch[kNoAllocMaxBatch * kMelBlocksPerChunk];
 constexpr int kMaxDevices = 64;
+constexpr int kGraphSlots = 4;                 // captured decode steps kept per self-attention bucket
 static float* g_scratch_ptr[kMaxDevices] = {};
 static std::mutex g_scratch_mutex;
 // one per GPU: every context and fork on a GPU shares that GPU's array, so calls on one GPU take turns
@@ -132,8 +133,12 @@ struct mw_ctx {
 
     // captured decode step
     // one captured step per self-attention context bucket (the launch geometry of that kernel follows the position)
-    hipGraph_t graph[kSelfAttnBuckets] = {}; hipGraphExec_t graph_exec[kSelfAttnBuckets] = {};
-    long graph_batch[kSelfAttnBuckets] = {}; int graph_logits[kSelfAttnBuckets] = {-1, -1, -1, -1};
+    // and, per bucket, up to kGraphSlots (batch size / forced length / kind of decode / logits flag) combinations kept
+    // side by side: a ragged last batch, or a fallback pass between greedy ones, does not throw the other's graphs
+    // away (a capture + instantiate of the ~260-launch step costs tens of ms per bucket)
+    hipGraph_t graph[kSelfAttnBuckets][kGraphSlots] = {}; hipGraphExec_t graph_exec[kSelfAttnBuckets][kGraphSlots] = {};
+    long graph_batch[kSelfAttnBuckets][kGraphSlots] = {}; int graph_logits[kSelfAttnBuckets][kGraphSlots] = {};
+    int graph_next[kSelfAttnBuckets] = {};                // slot the next new combination of a bucket takes (round robin)
 
     // timing
     hipEvent_t ev[6]{};
@@ -368,10 +373,11 @@ extern "C" void mw_destroy(mw_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < kSelfAttnBuckets; ++i) {
-        if (ctx->graph_exec[i]) (void)hipGraphExecDestroy(ctx->graph_exec[i]);
-        if (ctx->graph[i]) (void)hipGraphDestroy(ctx->graph[i]);
-    }
+    for (int i = 0; i < kSelfAttnBuckets; ++i)
+        for (int j = 0; j < kGraphSlots; ++j) {
+            if (ctx->graph_exec[i][j]) (void)hipGraphExecDestroy(ctx->graph_exec[i][j]);
+            if (ctx->graph[i][j]) (void)hipGraphDestroy(ctx->graph[i][j]);
+        }
     for (void* p : ctx->allocs) (void)hipFree(p);
     if (ctx->stage) (void)hipFree(ctx->stage);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -422,10 +428,11 @@ extern "C" int mw_fork_sized(mw_ctx* parent, int max_batch, mw_ctx** out) {
 static int drop_graphs(mw_ctx* ctx) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < kSelfAttnBuckets; ++i) {
-        if (ctx->graph_exec[i]) { (void)hipGraphExecDestroy(ctx->graph_exec[i]); ctx->graph_exec[i] = nullptr; }
-        if (ctx->graph[i]) { (void)hipGraphDestroy(ctx->graph[i]); ctx->graph[i] = nullptr; }
-    }
+    for (int i = 0; i < kSelfAttnBuckets; ++i)
+        for (int j = 0; j < kGraphSlots; ++j) {
+            if (ctx->graph_exec[i][j]) { (void)hipGraphExecDestroy(ctx->graph_exec[i][j]); ctx->graph_exec[i][j] = nullptr; }
+            if (ctx->graph[i][j]) { (void)hipGraphDestroy(ctx->graph[i][j]); ctx->graph[i][j] = nullptr; }
+        }
     return MW_OK;
 }
 
@@ -1032,16 +1039,24 @@ static int poll_finished(mw_ctx* ctx, int n, int need, bool* all_done) {
 static int ensure_graph(mw_ctx* ctx, int B, bool want_logits, const FinalizeParams& fp, long key, int n_keys, hipGraphExec_t* out,
                         const BeamParams* beam = nullptr, const SampleParams* samp = nullptr) {
     const int b = dec_self_attn_bucket(n_keys);
-    if (!(ctx->graph_exec[b] && ctx->graph_batch[b] == key && ctx->graph_logits[b] == (int)want_logits)) {
-        if (ctx->graph_exec[b]) { (void)hipGraphExecDestroy(ctx->graph_exec[b]); ctx->graph_exec[b] = nullptr; }
-        if (ctx->graph[b]) { (void)hipGraphDestroy(ctx->graph[b]); ctx->graph[b] = nullptr; }
-        HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        enqueue_step(ctx, B, want_logits, fp, n_keys, beam, samp);
-        HIPCHK(hipStreamEndCapture(ctx->stream, &ctx->graph[b]));
-        HIPCHK(hipGraphInstantiate(&ctx->graph_exec[b], ctx->graph[b], nullptr, nullptr, 0));
-        ctx->graph_batch[b] = key; ctx->graph_logits[b] = (int)want_logits;
+    for (int j = 0; j < kGraphSlots; ++j)
+        if (ctx->graph_exec[b][j] && ctx->graph_batch[b][j] == key && ctx->graph_logits[b][j] == (int)want_logits) {
+            *out = ctx->graph_exec[b][j];
+            return MW_OK;
+        }
+    const int j = ctx->graph_next[b];
+    ctx->graph_next[b] = (j + 1) % kGraphSlots;
+    if (ctx->graph_exec[b][j]) {           // the slot's old step may still be queued on the stream
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        (void)hipGraphExecDestroy(ctx->graph_exec[b][j]); ctx->graph_exec[b][j] = nullptr;
     }
-    *out = ctx->graph_exec[b];
+    if (ctx->graph[b][j]) { (void)hipGraphDestroy(ctx->graph[b][j]); ctx->graph[b][j] = nullptr; }
+    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_step(ctx, B, want_logits, fp, n_keys, beam, samp);
+    HIPCHK(hipStreamEndCapture(ctx->stream, &ctx->graph[b][j]));
+    HIPCHK(hipGraphInstantiate(&ctx->graph_exec[b][j], ctx->graph[b][j], nullptr, nullptr, 0));
+    ctx->graph_batch[b][j] = key; ctx->graph_logits[b][j] = (int)want_logits;
+    *out = ctx->graph_exec[b][j];
     return MW_OK;
 }
 
@@ -1433,6 +1448,43 @@ extern "C" int mw_set_encoded(mw_ctx* ctx, int batch) {
     int r = check_batch(ctx, batch, "mw_set_encoded");
     if (r) return r;
     ctx->enc_batch = batch;
+    return MW_OK;
+}
+
+extern "C" int mw_read_cross_kv(mw_ctx* ctx, int layer, int sequence, float* k_out, float* v_out) {
+    if (!ctx) return MW_ERR_ARG;
+    const mw_model_desc& d = ctx->d;
+    if (!k_out || !v_out) return fail(ctx, MW_ERR_ARG, "mw_read_cross_kv: null output");
+    if (layer < 0 || layer >= d.dec_layers) return fail(ctx, MW_ERR_ARG, "mw_read_cross_kv: layer out of range");
+    if (sequence < 0 || sequence >= ctx->enc_batch) return fail(ctx, MW_ERR_STATE, "mw_read_cross_kv: sequence is not among those encoded last");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const size_t per_seq = (size_t)d.n_heads * d.n_audio_ctx * kHeadDim;                 // elements of one sequence in one layer
+    const size_t at = ((size_t)layer * ctx->max_batch + sequence) * per_seq;
+    if (ctx->kv8) {
+        const size_t rows = per_seq / kHeadDim;
+        std::vector<uint8_t> codes(per_seq);
+        std::vector<float> scales(rows);
+        const uint8_t* src8[2] = {ctx->crossK8, ctx->crossV8};
+        const float* srcs[2] = {ctx->crossKs, ctx->crossVs};
+        float* dst[2] = {k_out, v_out};
+        for (int w = 0; w < 2; ++w) {
+            HIPCHK(hipMemcpy(codes.data(), src8[w] + at, per_seq, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(scales.data(), srcs[w] + at / kHeadDim, rows * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < per_seq; ++i) {
+                const uint8_t c = codes[i];
+                const int e = (c >> 3) & 15, m = c & 7;
+                const float v = e == 0 ? ldexpf((float)m, -9) : ldexpf(1.0f + m * 0.125f, e - 7);
+                dst[w][i] = ((c & 0x80) ? -v : v) * scales[i / kHeadDim];
+            }
+        }
+        return MW_OK;
+    }
+    std::vector<f16> h(per_seq);
+    HIPCHK(hipMemcpy(h.data(), ctx->crossK + at, per_seq * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < per_seq; ++i) k_out[i] = (float)h[i];
+    HIPCHK(hipMemcpy(h.data(), ctx->crossV + at, per_seq * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < per_seq; ++i) v_out[i] = (float)h[i];
     return MW_OK;
 }
 

@@ -174,9 +174,13 @@ __device__ __forceinline__ float quad_column_sum(float v) {
 
 // Three workgroups per CU (158 VGPRs instead of the 200 the compiler takes when left alone, no spills): with a
 // third wave per SIMD the MFMA, exp and LDS phases of different waves overlap; 401 -> 316 us at batch 16.
+// VARLEN (a packed batch of recordings of different lengths, the forced aligner's): batch element b has keys_of[b] <= T
+// keys (and as many queries that matter); its rows still lie T apart.  T below is then the element's own length
+// wherever keys are counted; workgroups whose queries all lie past it have nothing to do.
+template <bool VARLEN>
 __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                             const f16* __restrict__ vT, f16* __restrict__ out, int H,
-                                                            int T, int Tpad) {
+                                                            int Tstride, int Tpad, const int* __restrict__ keys_of) {
     __shared__ __attribute__((aligned(16))) f16 lds[2][2][AKV * 64];     // [buffer][K | V^T][64 x 64] = 32 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -187,11 +191,15 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
         const int nwg = gridDim.x, qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
     }
-    const int nqt = (T + AQ - 1) / AQ;
+    const int nqt = (Tstride + AQ - 1) / AQ;
     const int bh = bid / nqt;
     const int q0 = (bid - bh * nqt) * AQ + wave * 32;
-    const f16* qb = q + (long)bh * T * 64;
-    const f16* kb = k + (long)bh * T * 64;
+    const int T = VARLEN ? keys_of[bh / H] : Tstride;
+    if constexpr (VARLEN) {
+        if ((bid - bh * nqt) * AQ >= T) return;                 // (workgroup-uniform, before any barrier)
+    }
+    const f16* qb = q + (long)bh * Tstride * 64;
+    const f16* kb = k + (long)bh * Tstride * 64;
     const f16* vb = vT + (long)bh * 64 * Tpad;
 
     // Q fragments (B operand: column = query, k = head-dim), straight from global.
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
         const float inv = 1.0f / quad_column_sum(lrun[qs]);
         const int row = q0 + qs * 16 + fr;
         if (row < T) {
-            f16* dst = out + ((long)b * T + row) * (H * 64) + h * 64 + 4 * fg;
+            f16* dst = out + ((long)b * Tstride + row) * (H * 64) + h * 64 + 4 * fg;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 *reinterpret_cast<half4*>(dst + dt * 16) =
@@ -439,8 +447,11 @@ void launch_bcast_rows(const float* table, float* x, int B, int rows, int D, hip
     hipLaunchKernelGGL(bcast_rows_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, table, x, per, total);
 }
 
-void launch_enc_attention(const f16* q, const f16* k, const f16* vT, f16* out, int B, int H, int T, int Tpad, hipStream_t s) {
-    hipLaunchKernelGGL(enc_attention_kernel, dim3(((T + AQ - 1) / AQ) * B * H), dim3(256), 0, s, q, k, vT, out, H, T, Tpad);
+void launch_enc_attention(const f16* q, const f16* k, const f16* vT, f16* out, int B, int H, int T, int Tpad, hipStream_t s,
+                          const int* keys_of) {
+    const dim3 grid(((T + AQ - 1) / AQ) * B * H);
+    if (keys_of) hipLaunchKernelGGL(enc_attention_kernel<true>, grid, dim3(256), 0, s, q, k, vT, out, H, T, Tpad, keys_of);
+    else hipLaunchKernelGGL(enc_attention_kernel<false>, grid, dim3(256), 0, s, q, k, vT, out, H, T, Tpad, keys_of);
 }
 
 void launch_convert(const void* src, int src_dtype, void* dst, int dst_is_f16, long n, hipStream_t s) {

@@ -84,7 +84,10 @@ void launch_layernorm_fp8(const float* x, const float* g, const float* b, uint8_
                           hipStream_t s);
 void launch_bcast_rows(const float* table, float* x, int B, int rows, int D, hipStream_t s);   // x[b][r][:] = table[r][:]
 // q,k [B][H][T][64], vT [B][H][64][Tpad] -> out [B*T][H*64] fp16
-void launch_enc_attention(const f16* q, const f16* k, const f16* vT, f16* out, int B, int H, int T, int Tpad, hipStream_t s);
+// keys_of (optional, device, int [B]): batch element b attends over its first keys_of[b] <= T positions only and only its
+// first keys_of[b] output rows are written (a packed batch of recordings of different lengths; the rest must hold finite values)
+void launch_enc_attention(const f16* q, const f16* k, const f16* vT, f16* out, int B, int H, int T, int Tpad, hipStream_t s,
+                          const int* keys_of = nullptr);
 
 // ---------------------------------------------------------------- weight import
 void launch_convert(const void* src, int src_dtype, void* dst, int dst_is_f16, long n, hipStream_t s);

@@ -196,6 +196,13 @@ class Engine:
         """Sequences 0 .. batch - 1 of this engine's cache have been filled by ``encode_into`` calls."""
         self._check(self._lib.mw_set_encoded(self._h, int(batch)), "mw_set_encoded")
 
+    def read_cross_kv(self, layer: int, sequence: int):
+        """(K, V) float32 [n_heads, n_audio_ctx, 64] that decoder layer ``layer`` holds for ``sequence`` (test hook)."""
+        shape = (self.dims.n_heads, self.dims.n_audio_ctx, 64)
+        k, v = np.empty(shape, np.float32), np.empty(shape, np.float32)
+        self._check(self._lib.mw_read_cross_kv(self._h, int(layer), int(sequence), _ptr(k), _ptr(v)), "mw_read_cross_kv")
+        return k, v
+
     def decode_greedy(self, batch: int, want_logits: bool = False):
         if self.opts is None:
             raise EngineError("set_decode_options first")

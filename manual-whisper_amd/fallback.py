@@ -22,8 +22,11 @@ The algorithm, per window:
 ``no_speech_threshold`` has no part here: whisperx cuts its windows with a voice-activity detector and does not use it.
 
 On the GPU a pass over ``n`` windows keeps their encoder state; every further temperature is one
-``Engine.decode_sample`` call in which only the failed windows are active, so a window that passes at temperature 0
-costs nothing afterwards.
+``Engine.decode_sample`` call in which only the failed windows are active: a window that has passed starts ended, so
+its cross-attention (the K/V stream, the largest share of a step's bytes) is skipped, but its rows still ride through
+the prompt prefill, the self-attention, the projections (whose weights stream once for all rows anyway) and the
+logits of every step; a change of ``best_of`` between temperatures (1 at temperature 0, 5 above) re-captures the
+step graphs once.
 """
 from __future__ import annotations
 

@@ -94,6 +94,9 @@ class Model:
         self.pool = None                    # built at the first call: its engines are sized to what the call needs
         self._pool_key = None
         self._opts_for = None
+        # measurement hook: decode rules used as they are instead of those derived from the language and the prompt
+        # (bench.py: synthetic weights never emit end-of-text on cue, so its rules suppress it)
+        self.fixed_options: Optional[DecodeOptions] = None
 
     def _pool_for(self, n_chunks: int, batch_size: int):
         """The engine pool for a job of `n_chunks` chunks in batches of `batch_size`; kept between calls and rebuilt
@@ -113,6 +116,15 @@ class Model:
         # the encoders whatever batch_size the caller picks
         cap = max(1, self.max_group_sequences // batch)
         group = max(1, min(self.group, n_batches, cap))
+        # Short jobs (a rank's share of a recording split over many GPUs): with two or three batches every batch is
+        # decoded on an engine of its own as soon as it is encoded, so that decoding overlaps the encoder passes that
+        # remain (large-v3, batches of 16, whole job: [1, 1] 456 ms against [2] 498; [1, 1, 1] 648 against [3] 748);
+        # from four batches on the fewest, largest groups win ([4] = [2, 2] 834; [4, 4] 1404 against [3, 3, 2] 1438;
+        # [7, 7] 2144 against [5, 5, 4] 2248).  One batch cannot be split to advantage: a greedy step over 16 sequences is
+        # a chain of ~260 launches whose length does not shrink with fewer sequences ([8 + 7] in one group 328 ms, as two
+        # groups 344, against 325 for the pass of 15).
+        if n_batches <= min(3, self.n_decoders):
+            group = 1
         n_groups = -(-n_batches // group)
         need = (batch, group, min(self.n_encoders, n_batches), min(self.n_decoders, n_groups))
         if kept and all(h >= n for h, n in zip(have[1:], need)):
@@ -143,6 +155,8 @@ class Model:
 
     # -- decoding rules ---------------------------------------------------------------
     def decode_options(self, language: str) -> DecodeOptions:
+        if self.fixed_options is not None:
+            return self.fixed_options
         if self.synthetic and self.dims.vocab < 51865:
             return synthetic_options(self.dims, max_new=min(self.max_new, 64))
         prompt_ids = ()

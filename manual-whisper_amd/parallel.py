@@ -81,3 +81,28 @@ def transcribe_sharded(transcribe_chunks: Callable[[np.ndarray], List[np.ndarray
         out.extend(unpack_rows(g[r]))
     assert len(out) == n, (len(out), n)
     return out
+
+
+def align_sharded(align_segments: Callable[[list], dict], segments: Sequence[dict]) -> dict:
+    """Forced alignment of a recording's segments over the ranks (reference transcribe.py:130-131 runs it on one
+    device): segments are independent, so rank r aligns the contiguous block ``shard_range`` gives it with
+    ``align_segments(block) -> {"segments": [...], "word_segments": [...]}`` and ONE gather of the (small, picklable)
+    blocks puts the whole result together, in order, on every rank.  A world of one just calls ``align_segments``."""
+    segments = list(segments)
+    try:
+        import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized()
+    except ImportError:
+        on = False
+    if not on or dist.get_world_size() == 1:
+        return align_segments(segments)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    a, b = shard_range(len(segments), rank, world)
+    mine = align_segments(segments[a:b]) if b > a else {"segments": [], "word_segments": []}
+    blocks = [None] * world
+    dist.all_gather_object(blocks, mine)
+    out = {"segments": [], "word_segments": []}
+    for blk in blocks:                                    # contiguous blocks: rank order is segment order
+        out["segments"] += blk["segments"]
+        out["word_segments"] += blk["word_segments"]
+    return out

@@ -187,6 +187,28 @@ def test_align_falls_back_to_the_segment_when_nothing_can_be_aligned():
     assert [(s["start"], s["end"]) for s in out["segments"]] == [(0.0, 0.5), (5.0, 6.0), (0.0, 0.5)]
 
 
+def test_align_keeps_the_other_segments_when_the_model_refuses_one(capsys):
+    """A segment the acoustic model cannot take (61 s with an aligner built for 60 s) falls back to its original
+    times like every other per-segment failure; the segments around it are aligned."""
+    from manual_whisper_amd.engine import EngineError
+    vocab = {"<pad>": 0, "a": 1, "b": 2}
+    meta = {"language": "en", "dictionary": vocab, "type": "huggingface"}
+
+    class _Limited(_ScriptedModel):
+        def emissions(self, wave):
+            if len(wave) > 60 * 16000:
+                raise EngineError("mw_align_segment failed (-1): n_samples exceeds max_samples")
+            return super().emissions(wave)
+
+    model = _Limited(vocab, ["<pad>", "a", "<pad>", "b", "<pad>"])
+    audio = np.zeros(16000 * 70, np.float32)
+    out = al.align([{"text": "ab", "start": 0.0, "end": 1.0}, {"text": "ab", "start": 2.0, "end": 63.0},
+                    {"text": "ab", "start": 64.0, "end": 65.0}], model, meta, audio, "cuda")
+    assert [len(s["words"]) for s in out["segments"]] == [1, 0, 1]
+    assert (out["segments"][1]["start"], out["segments"][1]["end"]) == (2.0, 63.0)
+    assert "max_samples" in capsys.readouterr().out
+
+
 def test_load_align_model_needs_a_local_directory(monkeypatch):
     monkeypatch.delenv("MW_ALIGN_MODEL", raising=False)
     with pytest.raises(FileNotFoundError, match="MW_ALIGN_MODEL"):
@@ -211,7 +233,7 @@ def _check_emissions(got, want, atol):
 
 @pytest.fixture(scope="module")
 def micro_aligner(micro_weights):
-    a = al.Aligner(CFG, device=0, max_seconds=4)
+    a = al.Aligner(CFG, device=0, max_seconds=4, n_streams=8, pack_seconds=32)
     a.load_weights(micro_weights)
     yield a
     a.close()
@@ -267,6 +289,61 @@ def test_gpu_segment_path_equals_emissions_then_search(micro_aligner):
         assert [p.score for p in got] == pytest.approx([p.score for p in want], rel=1e-6)
     with pytest.raises(mw.EngineError, match="outside the vocabulary"):
         micro_aligner.segment_path(wave, [40], 0)
+
+
+@pytest.mark.gpu
+def test_gpu_pack_of_segments_equals_one_segment_at_a_time(micro_aligner):
+    """mw_align_segments: segments of different lengths through the model in ONE pass (slices of the longest one, the
+    positional convolution and the attention on each segment's own frames) give every segment the path and the scores
+    it gets alone, whatever shares its pack and wherever it stands in it."""
+    lens = [63999, 19200, 400, 12345, 30001, 6000, 47777]
+    waves = [_wave(f"p{i}", n) for i, n in enumerate(lens)]
+    tokens = [[5, 9, -1, 7, 7, 30, -1], [12], [3], list(range(1, 30)), [3] * 120, [8, -1, 8], [2, 4, 6, 8, 10] * 4]
+    alone = [micro_aligner.segment_path(w, t, 0) for w, t in zip(waves, tokens)]
+    assert alone[2][0] is not None and alone[4][0] is None          # one frame, one token: a path; 120 tokens in 93 frames: none
+    for order in (list(range(7)), [6, 2, 0, 5, 3, 1, 4], [1, 3], [4, 0]):
+        ws, ts = [waves[i] for i in order], [tokens[i] for i in order]
+        assert micro_aligner.pack_fits([len(w) for w in ws], [len(t) for t in ts]) == (len(order) * max(len(w) for w in ws) <= 32 * 16000)
+        if not micro_aligner.pack_fits([len(w) for w in ws], [len(t) for t in ts]):
+            continue
+        got = micro_aligner.segments_path(ws, ts, 0)
+        for i, (path, n) in zip(order, got):
+            want, n_want = alone[i]
+            assert n == n_want
+            if want is None:
+                assert path is None
+                continue
+            assert [(p.token_index, p.time_index) for p in path] == [(p.token_index, p.time_index) for p in want], i
+            assert [p.score for p in path] == pytest.approx([p.score for p in want], rel=2e-3, abs=1e-6)
+    assert not micro_aligner.pack_fits([63999] * 9, [3] * 9)         # 9 slices of 4 s do not fit 32 s
+    with pytest.raises(mw.EngineError, match="max_samples"):
+        micro_aligner.segments_path([np.zeros(64001, np.float32)], [[3]], 0)
+
+
+@pytest.mark.gpu
+def test_gpu_align_packs_segments_and_keeps_their_order(micro_aligner):
+    """align() over segments of mixed lengths: packed passes (longest first) and one segment at a time (the model
+    stripped of its pack interface) give the same result, in the segments' order."""
+    vocab = localckpt.synthetic_ctc_vocab(CFG["vocab_size"])
+    meta = {"language": "zh", "dictionary": vocab, "type": "huggingface"}
+    chars = [c for c in vocab if len(c) == 1 and c.isalpha()]
+    rng = np.random.default_rng(5)
+    audio = _wave("mix", 16000 * 30, seed=9)
+    bounds = [0.0, 3.9, 4.3, 8.2, 9.0, 12.5, 12.9, 16.8, 20.0, 23.5, 27.4, 30.0]
+    segs = [{"text": "".join(rng.choice(chars, 1 + int(3 * (b - a)))), "start": a, "end": b} for a, b in zip(bounds[:-1], bounds[1:])]
+    packed = al.align(segs, micro_aligner, meta, audio, "cuda")
+
+    class _OneAtATime:
+        n_streams = 1
+
+        def segment_path(self, wave, tokens, blank_id=0):
+            return micro_aligner.segment_path(wave, tokens, blank_id)
+
+    single = al.align(segs, _OneAtATime(), meta, audio, "cuda")
+    assert [s["text"] for s in packed["segments"]] == [s["text"] for s in single["segments"]] == [s["text"] for s in segs]
+    assert [(w["word"], w.get("start"), w.get("end")) for w in packed["word_segments"]] == \
+           [(w["word"], w.get("start"), w.get("end")) for w in single["word_segments"]]
+    assert [w["score"] for w in packed["word_segments"]] == pytest.approx([w["score"] for w in single["word_segments"]], abs=2e-3)
 
 
 @pytest.mark.gpu
@@ -333,6 +410,14 @@ def test_gpu_full_size_model_matches_the_oracle():
         a.load_weights(w)
         got = a.emissions(wave)
         got30 = a.emissions(np.tile(wave, 10))                         # the longest segment the path produces: 30 s
+        # a pack at full size: 30 s, 3 s and 11 s in one pass, each as it is alone
+        waves = [np.tile(wave, 10), wave, np.tile(wave, 4)[: 16000 * 11]]
+        toks = [list(range(5, 105)), [7, 8, 9], list(range(200, 240))]
+        alone = [a.segment_path(w_, t_, 0) for w_, t_ in zip(waves, toks)]
+        packed = a.segments_path(waves, toks, 0)
+        for (p1, n1), (p2, n2) in zip(alone, packed):
+            assert n1 == n2 and [(p.token_index, p.time_index) for p in p1] == [(p.token_index, p.time_index) for p in p2]
+            assert [p.score for p in p2] == pytest.approx([p.score for p in p1], rel=5e-3, abs=1e-6)
     finally:
         a.close()
     want = ref.Wav2Vec2Oracle(cfg, w).emissions(wave)

@@ -14,7 +14,7 @@ from manual_whisper_amd import synth
 from manual_whisper_amd.decode_options import synthetic_options
 from oracle.whisper_ref import WhisperOracle, log_mel
 
-from test_gpu_parity import ENC_ATOL, LOGIT_ATOL, assert_ids_match_up_to_ties
+from test_gpu_parity import ENC_ATOL, LOGIT_ATOL, TIE_GAP, assert_ids_match_up_to_ties
 
 pytestmark = pytest.mark.gpu
 
@@ -78,6 +78,14 @@ def test_config3_large_v3_one_chunk_vs_oracle(large):
                               opts.begin_suppress, return_logits=True)
     assert np.abs(logits[0] - wlog[0]).max() < 2 * LOGIT_ATOL
     assert_ids_match_up_to_ties(ids, wi, orc.last_margins)
+    # the cached cross-attention K/V of the first, a middle and the last decoder layer, read back through the C ABI
+    want = orc.cross_kv(enc_ref)
+    near = orc.cross_kv(enc)
+    for layer in (0, 15, 31):
+        k, v = eng.read_cross_kv(layer, 0)
+        for got, ref, ref_near in ((k, want[layer][0][0], near[layer][0][0]), (v, want[layer][1][0], near[layer][1][0])):
+            assert np.abs(got - ref).max() < 2 * ENC_ATOL, (layer, float(np.abs(got - ref).max()))
+            assert np.abs(got - ref_near).max() < 2.5e-3 + 1e-3 * np.abs(ref_near).max()     # fp16 rounding of the oracle's value
 
 
 def _rows_vs_oracle(eng, orc, dims, pcm, rows, n_new, enc_rows=None, enc_atol=None):
@@ -130,7 +138,7 @@ def test_config3_large_v3_batch16_rows_vs_oracle(large):
     first_err, path_err, forced_err, same = _rows_vs_oracle(eng, orc, dims, pcm, [0, 5, 10, 15], 32, enc_atol=2 * ENC_ATOL)
     assert first_err < LOGIT_ATOL, first_err
     assert path_err < 2 * LOGIT_ATOL and forced_err < 2 * LOGIT_ATOL, (path_err, forced_err)
-    assert same >= 2
+    assert same == 4           # measured: 4/4 (a row may only part at an oracle near-tie, which these rows do not have)
 
 
 def test_config3_large_v3_decode_group_rows_vs_oracle(large):
@@ -169,7 +177,12 @@ def test_config3_large_v3_decode_group_rows_vs_oracle(large):
         print(f"decode group of 112, rows {rows}: first-position logits {first_err:.2e}, on-path logits {path_err:.2e}, "
               f"{same}/4 rows identical to the oracle over {n_new} tokens, {agree}/112 identical to passes of 16")
         assert first_err < LOGIT_ATOL and path_err < 2 * LOGIT_ATOL, (first_err, path_err)
-        assert same >= 2 and agree >= 100 and (by16[:, :3] == ids[:, :3]).all()
+        # measured: 4/4 rows on the oracle's path and 111/112 identical to passes of 16 (the 112th parts at a near-tie)
+        assert same == 4 and agree >= 110
+        for r in np.nonzero((by16 != ids).any(axis=1))[0]:      # parting from the pass of 16 only at a near-tie of its own logits
+            n = int(np.nonzero(by16[r] != ids[r])[0][0])
+            gap = float(logits[n, r, ids[r, n]] - logits[n, r, by16[r, n]])
+            assert abs(gap) < TIE_GAP, (int(r), n, gap)
     finally:
         dec.close()
 

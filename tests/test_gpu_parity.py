@@ -93,6 +93,30 @@ def test_forced_logits_vs_oracle(setup):
     assert np.abs(walked - got).max() < LOGIT_ATOL
 
 
+KV_ATOL = 2e-2      # a projection of the encoder output (held to ENC_ATOL per element) rounded to fp16; measured 6e-3.  The tight
+                    # check is the one against the oracle's projection of the engine's OWN encoder output below
+
+
+def test_cross_kv_cache_vs_oracle(setup):
+    """The cached cross-attention K/V themselves (every layer, every sequence), read back through the C ABI: against the
+    oracle's projection of the oracle's encoder output, and to fp16 rounding against its projection of the ENGINE's
+    encoder output (K has no bias, V has one; heads split as [H][T][64])."""
+    eng, orc, B, dims = setup["eng"], setup["orc"], setup["B"], setup["dims"]
+    enc = eng.encode(B, mel=setup["mel_ref"])
+    want = orc.cross_kv(setup["enc_ref"])
+    near = orc.cross_kv(enc)
+    for layer in range(dims.dec_layers):
+        for b in range(B):
+            k, v = eng.read_cross_kv(layer, b)
+            assert k.shape == (dims.n_heads, dims.n_audio_ctx, 64)
+            assert np.abs(k - want[layer][0][b]).max() < KV_ATOL and np.abs(v - want[layer][1][b]).max() < KV_ATOL
+            for got, ref in ((k, near[layer][0][b]), (v, near[layer][1][b])):
+                # the product accumulates in fp32 over fp16 inputs: what is stored is the fp16 rounding of (nearly) the oracle's value
+                assert np.abs(got - ref).max() < 2.5e-3 + 1e-3 * np.abs(ref).max()
+    with pytest.raises(Exception, match="sequence"):
+        eng.read_cross_kv(0, B)
+
+
 @pytest.mark.parametrize("graph", [0, 1])
 def test_greedy_ids_identical_to_fixture(setup, graph):
     eng, g, B = setup["eng"], setup["g"], setup["B"]

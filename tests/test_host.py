@@ -212,6 +212,19 @@ def take(a, b):
 out = parallel.transcribe_sharded(fake, take, max_new=5, n_items=len(wins))
 assert len(out) == n and all((a == b).all() for a, b in zip(out, want)), (out, want)
 assert taken == ([parallel.shard_range(n, dist.get_rank(), 2)] if parallel.shard_range(n, dist.get_rank(), 2)[1] > parallel.shard_range(n, dist.get_rank(), 2)[0] else [])
+# forced alignment sharded the same way: each rank "aligns" its block, one gather, order kept on every rank
+segs = [{"text": "s%%d" %% i, "start": float(i), "end": i + 0.5} for i in range(n)]
+seen = []
+def fake_align(block):
+    seen.append([s_["text"] for s_ in block])
+    words = [{"word": s_["text"] + w, "start": s_["start"], "end": s_["end"], "score": 1.0} for s_ in block for w in ("a", "b")]
+    return {"segments": [dict(s_, words=[w for w in words if w["word"].startswith(s_["text"] + "a") or w["word"].startswith(s_["text"] + "b")]) for s_ in block],
+            "word_segments": words}
+got = parallel.align_sharded(fake_align, segs)
+a_, b_ = parallel.shard_range(n, dist.get_rank(), 2)
+assert seen == ([[s_["text"] for s_ in segs[a_:b_]]] if b_ > a_ else []), seen
+assert [s_["text"] for s_ in got["segments"]] == [s_["text"] for s_ in segs]
+assert [w["word"] for w in got["word_segments"]] == [s_["text"] + w for s_ in segs for w in ("a", "b")]
 print("rank", dist.get_rank(), "ok")
 dist.destroy_process_group()
 '''

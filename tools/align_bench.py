@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Time the forced-alignment acoustic model (wav2vec2-large-xlsr-53 geometry, synthetic weights) on one GPU:
 ms per mw_align_emissions call for segments of 5, 15 and 30 s, the host search (mw_align_path) beside it, and align()
-over 48 windows of 30 s with MW_ALIGN_STREAMS (default 8) segments in flight."""
+over 48 windows of 30 s in packs of MW_ALIGN_PACK seconds (default 240: eight windows per pass; 30: one window per
+pass, the earlier arrangement) with MW_ALIGN_STREAMS (default 3) passes in flight."""
 import json
 import os
 import sys
@@ -18,9 +19,10 @@ from manual_whisper_amd import alignment as al, localckpt, synth  # noqa: E402
 def main():
     cfg = localckpt.wav2vec2_config("w2v-large")
     w = localckpt.make_wav2vec2_weights_np(cfg, 77)
-    a = al.Aligner(cfg, device=0, max_seconds=30, n_streams=int(os.environ.get("MW_ALIGN_STREAMS", "8")))
+    a = al.Aligner(cfg, device=0, max_seconds=30, n_streams=int(os.environ.get("MW_ALIGN_STREAMS", "3")),
+                   pack_seconds=int(os.environ.get("MW_ALIGN_PACK", "240")))
     a.load_weights(w)
-    out = {"n_streams": a.n_streams}
+    out = {"n_streams": a.n_streams, "pack_seconds": a.desc.max_samples // 16000}
     for sec in (5, 15, 30):
         wave = synth.hash_uniform_np(sec * 16000, "wave.bench", 3) * np.float32(0.6)
         a.emissions(wave)
@@ -42,7 +44,7 @@ def main():
     audio = np.tile(synth.hash_uniform_np(30 * 16000, "wave.bench", 5) * np.float32(0.6), n_seg)
     rng = np.random.default_rng(1)
     segs = [{"text": "".join(rng.choice(chars, 150)), "start": 30.0 * i, "end": 30.0 * (i + 1)} for i in range(n_seg)]
-    al.align(segs[:4], a, meta, audio, "cuda")
+    al.align(segs[:24], a, meta, audio, "cuda")
     t = time.perf_counter()
     res = al.align(segs, a, meta, audio, "cuda")
     dt = time.perf_counter() - t
