@@ -50,7 +50,7 @@ class Aligner:
     copy of the workspaces with its own stream (``mw_align_fork``; the weights are shared).  One segment is about
     1500 frames, a fraction of what fills the GPU."""
 
-    def __init__(self, cfg: dict, device: int = 0, max_seconds: int = MAX_ALIGN_SECONDS, n_streams: int = 3, pack_seconds: int = 240):
+    def __init__(self, cfg: dict, device: int = 0, max_seconds: int = MAX_ALIGN_SECONDS, n_streams: int = 4, pack_seconds: int = 240):
         if cfg.get("feat_extract_norm", "group") != "layer" or not cfg.get("do_stable_layer_norm", False) or not cfg.get("conv_bias", False):
             raise EngineError("only the wav2vec2 variant with a layer-norm feature extractor, convolution biases and stable "
                               "layer norm (wav2vec2-large-xlsr-53 and its fine-tunes) is built")
@@ -160,7 +160,7 @@ class Aligner:
             raise EngineError(f"mw_align_segment failed ({rc}): {self._lib.mw_align_last_error(h).decode()}")
         if rc == -2:
             return None, n.value
-        return [Point(int(j), t, float(p)) for t, (j, p) in enumerate(zip(idx[: n.value], sc[: n.value]))], n.value
+        return PathArrays(idx[: n.value].copy(), sc[: n.value].copy()), n.value
 
     MAX_PACK_SEGMENTS = 32
 
@@ -204,7 +204,7 @@ class Aligner:
             if status[b] != 0:
                 out.append((None, T))
             else:
-                out.append(([Point(int(j), t, float(p)) for t, (j, p) in enumerate(zip(idx[at: at + T], sc[at: at + T]))], T))
+                out.append((PathArrays(idx[at: at + T].copy(), sc[at: at + T].copy()), T))
             at += T
         return out
 
@@ -272,6 +272,29 @@ class Point:
     score: float
 
 
+class PathArrays:
+    """A path as the library returns it: token index and score per frame, as arrays.  Reads like the list of
+    ``Point`` it stands for (iteration, indexing, length), and ``merge_repeats`` takes it without building one object
+    per frame (a 30 s segment has 1499)."""
+    __slots__ = ("token_index", "score")
+
+    def __init__(self, token_index: np.ndarray, score: np.ndarray):
+        self.token_index, self.score = token_index, score
+
+    def __len__(self) -> int:
+        return int(self.token_index.shape[0])
+
+    def __getitem__(self, t):
+        if isinstance(t, slice):
+            return [self[i] for i in range(*t.indices(len(self)))]
+        if t < 0:
+            t += len(self)
+        return Point(int(self.token_index[t]), int(t), float(self.score[t]))
+
+    def __iter__(self):
+        return (Point(int(j), t, float(p)) for t, (j, p) in enumerate(zip(self.token_index, self.score)))
+
+
 @dataclass
 class Segment:
     label: str
@@ -284,7 +307,7 @@ class Segment:
         return self.end - self.start
 
 
-def ctc_path(emission: np.ndarray, tokens: Sequence[int], blank_id: int = 0) -> Optional[List[Point]]:
+def ctc_path(emission: np.ndarray, tokens: Sequence[int], blank_id: int = 0) -> Optional["PathArrays"]:
     """The most likely monotone path of `tokens` (-1: wildcard, a character outside the vocabulary, which scores the
     best non-blank entry of a frame) through the emissions: one Point per frame, or None when there are fewer frames
     than tokens.  Trellis and walk back run in libmwhip.so (``mw_align_path``), in float32 like the torch code of
@@ -300,11 +323,19 @@ def ctc_path(emission: np.ndarray, tokens: Sequence[int], blank_id: int = 0) -> 
         return None
     if rc != 0:
         raise EngineError(f"mw_align_path failed ({rc}): bad argument")
-    return [Point(int(j), t, float(p)) for t, (j, p) in enumerate(zip(idx, sc))]
+    return PathArrays(idx, sc)
 
 
 def merge_repeats(path: Sequence[Point], transcript: str) -> List[Segment]:
     """Runs of one token index -> one segment [first frame, last frame + 1) scored by the mean point score."""
+    if isinstance(path, PathArrays):
+        idx = path.token_index
+        if idx.shape[0] == 0:
+            return []
+        starts = np.concatenate(([0], np.nonzero(idx[1:] != idx[:-1])[0] + 1))
+        ends = np.concatenate((starts[1:], [idx.shape[0]]))
+        sums = np.add.reduceat(path.score.astype(np.float64), starts)       # in frame order, in double, as the loop below adds them
+        return [Segment(transcript[int(idx[a])], int(a), int(b), float(sm / (b - a))) for a, b, sm in zip(starts, ends, sums)]
     i1, i2, segments = 0, 0, []
     while i1 < len(path):
         while i2 < len(path) and path[i1].token_index == path[i2].token_index:
@@ -477,12 +508,10 @@ def align(transcript: Sequence[dict], model: Aligner, align_model_metadata: dict
         for sstart, send in prep["sentence_spans"]:
             cur = chars[sstart: send + 1]                       # inclusive of `send`, as whisperx selects them
             words = []
-            seen = []
+            by_word: Dict[int, list] = {}                       # word index -> its characters, words in order of appearance
             for c in cur:
-                if c["word-idx"] not in seen:
-                    seen.append(c["word-idx"])
-            for w in seen:
-                wchars = [c for c in cur if c["word-idx"] == w]
+                by_word.setdefault(c["word-idx"], []).append(c)
+            for wchars in by_word.values():
                 wtext = "".join(c["char"] for c in wchars).strip()
                 if not wtext:
                     continue
@@ -537,13 +566,17 @@ def align(transcript: Sequence[dict], model: Aligner, align_model_metadata: dict
                 packs.append([(i, t)])
 
         def run_pack(pack):
+            """A pack through the model and the search, then its segments' words and sentences (in the worker: one pack's
+            host work runs beside another pack's acoustic model)."""
             if len(pack) == 1 and not model.pack_fits([len(pack[0][1]["wave"])], [len(pack[0][1]["tokens"])]):
-                return [run_one(pack[0][1])]                    # too long or too many characters for a pack: the single-segment call decides
-            try:
-                return model.segments_path([t["wave"] for _, t in pack], [t["tokens"] for _, t in pack], blank_id)
-            except EngineError as e:
-                print(f"Failed to align a pack of {len(pack)} segments ({e}): aligning them one at a time...")
-                return [run_one(t) for _, t in pack]
+                res = [run_one(pack[0][1])]                     # too long or too many characters for a pack: the single-segment call decides
+            else:
+                try:
+                    res = model.segments_path([t["wave"] for _, t in pack], [t["tokens"] for _, t in pack], blank_id)
+                except EngineError as e:
+                    print(f"Failed to align a pack of {len(pack)} segments ({e}): aligning them one at a time...")
+                    res = [run_one(t) for _, t in pack]
+            return [finish(t, r) for (_, t), r in zip(pack, res)]
 
         if workers > 1 and len(packs) > 1:
             with ThreadPoolExecutor(max_workers=workers) as pool:
@@ -551,16 +584,19 @@ def align(transcript: Sequence[dict], model: Aligner, align_model_metadata: dict
         else:
             results = [run_pack(p) for p in packs]
         for pack, res in zip(packs, results):
-            for (i, t), r in zip(pack, res):
-                parts[i] = finish(t, r)
+            for (i, _), part in zip(pack, res):
+                parts[i] = part
     else:
+        def run_and_finish(it):
+            return finish(it[1], run_one(it[1]))
+
         if workers > 1 and len(todo) > 1:
             with ThreadPoolExecutor(max_workers=workers) as pool:
-                results = list(pool.map(lambda it: run_one(it[1]), todo))
+                results = list(pool.map(run_and_finish, todo))
         else:
-            results = [run_one(t) for _, t in todo]
-        for (i, t), r in zip(todo, results):
-            parts[i] = finish(t, r)
+            results = [run_and_finish(it) for it in todo]
+        for (i, _), part in zip(todo, results):
+            parts[i] = part
     aligned_segments: List[dict] = [seg for part in parts for seg in part]
 
     word_segments: List[dict] = []

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mw;
@@ -558,20 +559,34 @@ static int align_pack(mw_aligner* a, int n_seg, const float* const* pcm, const i
     ACHK(hipGetLastError());
     ACHK(hipMemcpyAsync(a->gath_host, a->gath_dev, need * 4, hipMemcpyDeviceToHost, s));
     ACHK(hipStreamSynchronize(s));
+    // the searches of a pack's segments are independent (225 k trellis cells for a 30 s window of 150 characters: 1.5 ms
+    // each): one host thread per segment beyond the first
+    std::vector<size_t> g_at(n_seg), f_at(n_seg);
+    std::vector<int> rc(n_seg, MW_OK);
     at = 0;
     size_t frame_at = 0;
-    int worst = MW_OK;
-    std::vector<float> blank;
     for (int b = 0; b < n_seg; ++b) {
+        n_frames[b] = frames[b];
+        g_at[b] = at; f_at[b] = frame_at;
+        at += (size_t)frames[b] * (n_tokens[b] + 1); frame_at += frames[b];
+    }
+    auto search = [&](int b) {
         const int T = frames[b], ld = n_tokens[b] + 1;
-        n_frames[b] = T;
         // column 0 of the gathered rows is the blank: copy it out so that the search reads two plain arrays
-        blank.resize(T);
-        for (int t = 0; t < T; ++t) blank[t] = a->gath_host[at + (size_t)t * ld];
-        const int r = path_search(blank.data(), a->gath_host + at + 1, T, n_tokens[b], ld, token_index + frame_at, score + frame_at);
-        if (status) status[b] = r;
-        if (r != MW_OK) worst = r;
-        at += (size_t)T * ld; frame_at += T;
+        std::vector<float> blank(T);
+        for (int t = 0; t < T; ++t) blank[t] = a->gath_host[g_at[b] + (size_t)t * ld];
+        rc[b] = path_search(blank.data(), a->gath_host + g_at[b] + 1, T, n_tokens[b], ld, token_index + f_at[b], score + f_at[b]);
+    };
+    {
+        std::vector<std::thread> workers;
+        for (int b = 1; b < n_seg; ++b) workers.emplace_back(search, b);
+        search(0);
+        for (auto& w : workers) w.join();
+    }
+    int worst = MW_OK;
+    for (int b = 0; b < n_seg; ++b) {
+        if (status) status[b] = rc[b];
+        if (rc[b] != MW_OK) worst = rc[b];
     }
     if (worst == MW_ERR_STATE) a->err = std::string(who) + ": no path (fewer frames than tokens)";
     return worst;

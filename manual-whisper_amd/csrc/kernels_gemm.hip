@@ -851,13 +851,17 @@ void launch_gemm(const GemmParams& p0, hipStream_t s) {
     // MI = 8 (256-row tile, one workgroup per CU) measured 35 % slower than MI = 4 (two per CU): with a
     // single barrier-synchronised workgroup on a CU nothing covers its waits.
     static const bool no256 = getenv("MW_GEMM_NO256") != nullptr;
+    // fewest 256x256 tiles for which that kernel is taken (one workgroup per CU, 256 CUs).  176 (two thirds of the CUs
+    // busy in one round) still beats the 128x128 form's round and a half: the aligner's 12000 x 1024 products (188
+    // tiles) took align() from 10.9 k to 11.5 k audio-s/s.  MW_GEMM_256_MIN_TILES: tuning runs.
+    static const long min256 = getenv("MW_GEMM_256_MIN_TILES") ? atol(getenv("MW_GEMM_256_MIN_TILES")) : 176;
     static const bool share = getenv("MW_GEMM_CS") != nullptr;          // tuning runs: the CU-sharing 256x128 form for every big product
     const int nk = p.K / BK;
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (p.K % BK != 0) launch_t<4, false>(p, s);
     else if (p.groups > 1) launch_t<4, true>(p, s);                  // grouped products: the 128x128 form only
     else if (share && tiles256 >= 256) launch_t<8, true>(p, s);
-    else if (!no256 && nk >= 2 && nk % 2 == 0 && tiles256 >= 256 && p.N % 8 == 0) launch_256<false>(p, s);
+    else if (!no256 && nk >= 2 && nk % 2 == 0 && tiles256 >= min256 && p.N % 8 == 0) launch_256<false>(p, s);
     else launch_t<4, true>(p, s);
 }
 

@@ -20,12 +20,65 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// GELU(x) = x * Phi(x), erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 rounding of the
+// result), the negative side through 1 + erf(z) = poly * exp(-z^2) so that nothing cancels: a dozen instructions
+// where erff takes about fifty.  The feature extractor applies it to 0.2 G elements per 30 s of audio.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float q = fmaf(1.061405429f, t, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    const float h = 0.5f * q * t * __expf(-z * z);       // 0.5 * (1 - erf(z))
+    return x * (x >= 0.f ? 1.0f - h : h);
+}
 
 // One wave per output frame (grid-stride over frames); lane l owns channels l, l + 64, ...  The C x K0 weights
 // sit in LDS, the K0 samples of a frame are the same address for every lane (one broadcast load each).
 // HBM: 4 bytes per sample in, 2 * C bytes per frame out (the output dominates: 98 MB for 30 s at C = 512).
 constexpr int kConv0MaxCPL = 8, kConv0MaxK = 16;
+// REGW: the lane's own weights (its C / 64 channels x K0 taps) live in registers for the whole launch (the usual
+// geometry, 512 channels x 10 taps, is 80 of them); otherwise they are read from LDS per frame.
+template <int CPL, int K0C>
+__global__ __launch_bounds__(256) void w2v_conv0_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, const float* __restrict__ g,
+                                                            const float* __restrict__ beta, f16* __restrict__ out, int T0, int S0) {
+    constexpr int C = CPL * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float wr[CPL][K0C], bb[CPL], gg[CPL], be[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        bb[i] = b[c]; gg[i] = g[c]; be[i] = beta[c];
+#pragma unroll
+        for (int j = 0; j < K0C; ++j) wr[i][j] = w[c * K0C + j];
+    }
+    const int stride = gridDim.x * 4;
+    for (int t = blockIdx.x * 4 + wave; t < T0; t += stride) {
+        float xv[K0C];
+#pragma unroll
+        for (int j = 0; j < K0C; ++j) xv[j] = x[(long)t * S0 + j];
+        float y[CPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            float a = bb[i];
+#pragma unroll
+            for (int j = 0; j < K0C; ++j) a += wr[i][j] * xv[j];          // same order of additions as the LDS form
+            y[i] = a;
+            s += a;
+        }
+        const float mean = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { y[i] -= mean; q += y[i] * y[i]; }
+        const float rstd = rsqrtf(wave_sum(q) / C + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) out[(long)t * C + lane + 64 * i] = (f16)gelu_erf(y[i] * rstd * gg[i] + be[i]);
+    }
+}
+
 __global__ __launch_bounds__(256) void w2v_conv0_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ g,
                                                         const float* __restrict__ beta, f16* __restrict__ out, int T0, int C,
@@ -71,18 +124,20 @@ __global__ __launch_bounds__(256) void w2v_conv0_kernel(const float* __restrict_
     }
 }
 
-// One wave per row; a lane owns the 8-half pieces lane, lane + 64, ... of the row (statistics in fp32).
+// One wave per row; a lane owns the 8-half pieces lane, lane + 64, ... of the row (statistics in fp32).  NV: pieces per
+// lane, D <= 512 * NV (the feature extractor's 512 channels: one piece, nothing to skip).
 constexpr int kLn16MaxV = 8;       // D <= 4096
+template <int NV>
 __global__ __launch_bounds__(256) void ln16_kernel(f16* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                    int rows, int D, float eps, int gelu) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     f16* xr = x + (long)row * D;
-    float v[kLn16MaxV][8];
+    float v[NV][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLn16MaxV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 8;
         if (c < D) {
             const half8 h = *reinterpret_cast<const half8*>(xr + c);
@@ -93,20 +148,23 @@ __global__ __launch_bounds__(256) void ln16_kernel(f16* __restrict__ x, const fl
     const float mean = wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLn16MaxV; ++i)
+    for (int i = 0; i < NV; ++i)
         if ((lane + 64 * i) * 8 < D) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { v[i][e] -= mean; q += v[i][e] * v[i][e]; }
         }
     const float rstd = rsqrtf(wave_sum(q) / D + eps);
 #pragma unroll
-    for (int i = 0; i < kLn16MaxV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 8;
         if (c < D) {
+            const float4 g0 = *reinterpret_cast<const float4*>(g + c), g1 = *reinterpret_cast<const float4*>(g + c + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(b + c), b1 = *reinterpret_cast<const float4*>(b + c + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             half8 h;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float o = v[i][e] * rstd * g[c + e] + b[c + e];
+                float o = v[i][e] * rstd * gg[e] + bb[e];
                 if (gelu) o = gelu_erf(o);
                 h[e] = (f16)o;
             }
@@ -185,11 +243,18 @@ void launch_w2v_conv0(const float* x, long n, const float* w, const float* b, co
                       int K0, int S0, hipStream_t s) {
     (void)n;
     const int grid = T0 < 4096 ? (T0 + 3) / 4 : 1024;
-    hipLaunchKernelGGL(w2v_conv0_kernel, dim3(grid > 0 ? grid : 1), dim3(256), (size_t)C * K0 * 4, s, x, w, b, g, beta, out, T0, C, K0, S0);
+    const dim3 gd(grid > 0 ? grid : 1);
+    if (C == 512 && K0 == 10)           // wav2vec2's feature extractor: the lane's 8 x 10 weights stay in registers
+        hipLaunchKernelGGL((w2v_conv0_reg_kernel<8, 10>), gd, dim3(256), 0, s, x, w, b, g, beta, out, T0, S0);
+    else
+        hipLaunchKernelGGL(w2v_conv0_kernel, gd, dim3(256), (size_t)C * K0 * 4, s, x, w, b, g, beta, out, T0, C, K0, S0);
 }
 
 void launch_ln16(f16* x, const float* g, const float* b, int rows, int D, float eps, int gelu, hipStream_t s) {
-    hipLaunchKernelGGL(ln16_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, rows, D, eps, gelu);
+    const dim3 grid((rows + 3) / 4);
+    if (D <= 512) hipLaunchKernelGGL(ln16_kernel<1>, grid, dim3(256), 0, s, x, g, b, rows, D, eps, gelu);
+    else if (D <= 1024) hipLaunchKernelGGL(ln16_kernel<2>, grid, dim3(256), 0, s, x, g, b, rows, D, eps, gelu);
+    else hipLaunchKernelGGL(ln16_kernel<kLn16MaxV>, grid, dim3(256), 0, s, x, g, b, rows, D, eps, gelu);
 }
 
 void launch_w2v_pos_pack(const float* x, f16* pack, int T, int D, int G, int K, hipStream_t s) {

@@ -2,7 +2,7 @@
 """Time the forced-alignment acoustic model (wav2vec2-large-xlsr-53 geometry, synthetic weights) on one GPU:
 ms per mw_align_emissions call for segments of 5, 15 and 30 s, the host search (mw_align_path) beside it, and align()
 over 48 windows of 30 s in packs of MW_ALIGN_PACK seconds (default 240: eight windows per pass; 30: one window per
-pass, the earlier arrangement) with MW_ALIGN_STREAMS (default 3) passes in flight."""
+pass, the earlier arrangement) with MW_ALIGN_STREAMS (default 4) passes in flight."""
 import json
 import os
 import sys
@@ -19,7 +19,7 @@ from manual_whisper_amd import alignment as al, localckpt, synth  # noqa: E402
 def main():
     cfg = localckpt.wav2vec2_config("w2v-large")
     w = localckpt.make_wav2vec2_weights_np(cfg, 77)
-    a = al.Aligner(cfg, device=0, max_seconds=30, n_streams=int(os.environ.get("MW_ALIGN_STREAMS", "3")),
+    a = al.Aligner(cfg, device=0, max_seconds=30, n_streams=int(os.environ.get("MW_ALIGN_STREAMS", "4")),
                    pack_seconds=int(os.environ.get("MW_ALIGN_PACK", "240")))
     a.load_weights(w)
     out = {"n_streams": a.n_streams, "pack_seconds": a.desc.max_samples // 16000}

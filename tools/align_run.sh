@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 timeout -k 10 900 python -u -m pytest tests/test_align.py -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/pytest_align.log 2>&1 || { tail -30 gpurun_out/pytest_align.log; exit 1; }
 tail -3 gpurun_out/pytest_align.log
 {
-for cfg in "30 8" "240 1" "240 2" "240 3" "120 3" "480 2"; do
+for cfg in "30 8" "240 2" "240 3" "240 4" "120 4" "360 3"; do
   set -- $cfg
   echo "== pack $1 s, $2 passes in flight"; MW_ALIGN_PACK=$1 MW_ALIGN_STREAMS=$2 timeout -k 10 300 python tools/align_bench.py
 done
