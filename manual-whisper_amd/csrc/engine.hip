@@ -316,8 +316,7 @@ static int alloc_work(mw_ctx* ctx) {
     ctx->n_parts = gemv_logits_parts(d.vocab);
     ALLOC(ctx->part_val, B * (size_t)ctx->n_parts); ALLOC(ctx->part_idx, B * (size_t)ctx->n_parts);
     ALLOC(ctx->mask_first, (size_t)d.vocab, true); ALLOC(ctx->mask_rest, (size_t)d.vocab, true);
-    const size_t xrows = std::max<size_t>(B, kPrefillSlabRows);      // query rows one cross-attention launch may carry
-    ALLOC(ctx->xpartial, xrows * H * kXattnSplit * 68); ALLOC(ctx->xtickets, xrows * H, true);
+    ALLOC(ctx->xpartial, B * H * kXattnSplit * 68); ALLOC(ctx->xtickets, B * H, true);
     const size_t seq_groups = (B + 15) / 16;                          // batches beyond 32 run as groups of 16 inside a launch
     ALLOC(ctx->skpartial, splitk_partial_floats(D) * seq_groups); ALLOC(ctx->sktickets, splitk_groups(D) * seq_groups, true);
     if (B > 32) ALLOC(ctx->dgpartial, decgemm_partial_floats((int)D, (int)F, (int)B));
@@ -1004,9 +1003,16 @@ static int run_prefill(mw_ctx* ctx, int B, int P, int beam = 1, int* src_rows = 
         {   GemmParams p = gemm(ctx->att, D, l.out, D); p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D; launch_gemm(p, s); }
         launch_layernorm(ctx->x, l.ln2.g, l.ln2.b, ctx->xn, nullptr, M, D, s);
         {   GemmParams p = gemm(ctx->xn, D, l.cq, D); p.scale = qscale; p.scale_ncols = D; p.C = cq; p.ldc = D; launch_gemm(p, s); }
-        for (int r0 = 0; r0 < M; r0 += kPrefillSlabRows) {
-            const int rows = std::min(kPrefillSlabRows, M - r0);
-            cross_attention(ctx, li, cq + (size_t)r0 * D, ctx->att + (size_t)r0 * D, rows, P * kv_rep, r0);
+        {   // every prompt row of a sequence against the cached encoder K/V of its recording, one pass of the keys
+            const size_t per_layer = (size_t)ctx->max_batch * d.n_audio_ctx * D;
+            if (ctx->kv8) {
+                const size_t per_layer_rows = (size_t)ctx->max_batch * d.n_audio_ctx * H;
+                launch_prefill_cross_attn8(cq, ctx->crossK8 + li * per_layer, ctx->crossV8 + li * per_layer, ctx->crossKs + li * per_layer_rows,
+                                           ctx->crossVs + li * per_layer_rows, ctx->att, B, P, H, d.n_audio_ctx, kv_rep, s);
+            } else {
+                launch_prefill_cross_attn(cq, ctx->crossK + li * per_layer, ctx->crossV + li * per_layer, ctx->att, B, P, H, d.n_audio_ctx,
+                                          kv_rep, s);
+            }
         }
         {   GemmParams p = gemm(ctx->att, D, l.co, D); p.out_mode = OUT_RESID_F32; p.C = ctx->x; p.ldc = D; launch_gemm(p, s); }
         launch_layernorm(ctx->x, l.ln3.g, l.ln3.b, ctx->xn, nullptr, M, D, s);

@@ -1752,6 +1752,230 @@ __global__ __launch_bounds__(256) void prefill_self_attn_kernel(const f16* __res
     out[((long)b * P + j) * D + h * 64 + lane] = (f16)(o / sum);
 }
 
+// Cross-attention of ALL prompt positions of one (sequence, head) over the cached encoder K/V
+// (modeling_whisper.py:486-492 for every prompt row at once).  One workgroup per (sequence, head, block of 128
+// prompt rows): the 1500 keys pass through LDS once, in tiles of 64, and serve every row of the block on the
+// matrix cores, where one single-query launch per row would pull the same 375 KB through the L2 for each of
+// them (75 prompt rows: 75 times).  Each wave owns 32 query rows (two 16-column tiles of the swapped product
+// S^T = K Q^T, so a lane's scores all belong to one query and the softmax statistics stay in the lane);
+// O^T = V^T P^T takes V^T from the row-major V tile with the transposing LDS read (ds_read_b64_tr_b16: lane
+// 4a+b of a 16-lane group addresses row a, columns 4b..4b+3 of a 4 x 16 block and receives column 4a+b).
+// V rows are 80 halfs apart in LDS: the 8 rows a 32-lane half reads then start 40 banks apart, on 8 distinct
+// 8-bank runs.  Waves whose rows lie past the prompt only help with the staging.
+// KV8: the cache holds e4m3 codes with one fp32 scale per row (cross_attn8_kernel's format); the codes go to the
+// matrix cores as they are (exact in fp16), the K scale multiplies the score and the V scale the probability, the
+// places where the single-query kernels apply them.
+// q: [sequences * P][H * 64] (scaled queries), out likewise; sequence b reads the K/V of recording b / kv_rep.
+constexpr int PFQ = 128, PFK = 64, PFVS = 80;
+constexpr float kPfLog2e = 1.4426950408889634f;
+constexpr float kPfRescaleGap = 6.0f;
+
+__device__ __forceinline__ int pf_swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+__device__ __forceinline__ float pf_column_max(float v) {          // over lanes l&15, +16, +32, +48
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float pf_column_sum(float v) {
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+}
+
+template <bool KV8>
+__global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* __restrict__ q, const void* __restrict__ kc,
+                                                                    const void* __restrict__ vc, const float* __restrict__ ks,
+                                                                    const float* __restrict__ vs, f16* __restrict__ out, int H,
+                                                                    int P, int T, int kv_rep) {
+    __shared__ __attribute__((aligned(16))) f16 ldsK[2][PFK * 64];
+    __shared__ __attribute__((aligned(16))) f16 ldsV[2][PFK * PFVS];
+    __shared__ __attribute__((aligned(16))) float ldsS[2][2][KV8 ? PFK : 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nqb = (P + PFQ - 1) / PFQ;
+    const int bh = blockIdx.x / nqb, qblock = blockIdx.x - bh * nqb;
+    const int seq = bh / H, h = bh - seq * H;
+    const long bh_kv = (long)(seq / kv_rep) * H + h;
+    const int q0 = qblock * PFQ + wave * 32;
+    const bool active = q0 < P;                 // wave-uniform
+    const int D = H * 64;
+    const f16* qbase = q + (long)seq * P * D + h * 64;
+
+    half8 qf[2][2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int row = min(q0 + qs * 16 + fr, P - 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[qs][s] = *reinterpret_cast<const half8*>(qbase + (long)row * D + s * 32 + fg * 8);
+    }
+
+    // staging: a thread moves two 8-element chunks of K and two of V per tile (16 bytes each, 8 in the e4m3 cache)
+    typedef typename std::conditional<KV8, uint2, uint4>::type Chunk;
+    Chunk rk[2], rv[2];
+    float rscale = 0.f;
+    const int ch = tid & 7;
+    auto gload = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = kv0 + (tid >> 3) + 32 * i;
+            const long off = (bh_kv * T + key) * 64 + ch * 8;
+            if constexpr (KV8) {
+                rk[i] = key < T ? *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(kc) + off) : make_uint2(0, 0);
+                rv[i] = key < T ? *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(vc) + off) : make_uint2(0, 0);
+            } else {
+                rk[i] = key < T ? *reinterpret_cast<const uint4*>(static_cast<const f16*>(kc) + off) : make_uint4(0, 0, 0, 0);
+                rv[i] = key < T ? *reinterpret_cast<const uint4*>(static_cast<const f16*>(vc) + off) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        if constexpr (KV8) {
+            if (tid < 2 * PFK) {
+                const int key = kv0 + (tid & (PFK - 1));
+                rscale = key < T ? (tid < PFK ? ks : vs)[bh_kv * T + key] : 0.f;
+            }
+        }
+    };
+    auto as_f16 = [](const Chunk& c) -> uint4 {
+        if constexpr (KV8) {
+            float f[8];
+            e4m3x8_to_f32(c, f);
+            const half8 hv = half8{(f16)f[0], (f16)f[1], (f16)f[2], (f16)f[3], (f16)f[4], (f16)f[5], (f16)f[6], (f16)f[7]};
+            return *reinterpret_cast<const uint4*>(&hv);
+        } else {
+            return c;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<uint4*>(&ldsK[buf][pf_swz(row, ch)]) = as_f16(rk[i]);
+            *reinterpret_cast<uint4*>(&ldsV[buf][row * PFVS + ch * 8]) = as_f16(rv[i]);
+        }
+        if constexpr (KV8) {
+            if (tid < 2 * PFK) ldsS[buf][tid >> 6][tid & (PFK - 1)] = rscale;
+        }
+    };
+
+    float4v o[4][2];           // [head-dim tile][query tile]: O^T
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i][0] = float4v{0, 0, 0, 0}; o[i][1] = float4v{0, 0, 0, 0}; }
+    // reference exponent (log2 units) and sum per query; the reference rises only when a tile exceeds it by
+    // more than kPfRescaleGap, so the accumulators are rarely rescaled after the first tile
+    float mrun[2] = {0.f, 0.f};
+    float lrun[2] = {0.f, 0.f};
+
+    const int ntile = (T + PFK - 1) / PFK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const int buf = it & 1, kv0 = it * PFK;
+        if (it + 1 < ntile) gload(kv0 + PFK);
+        if (active) {
+            // ---- S^T tiles: [key tile i][query tile qs]
+            float4v sc[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sc[i][0] = float4v{0, 0, 0, 0}; sc[i][1] = float4v{0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const half8 kf = *reinterpret_cast<const half8*>(&ldsK[buf][pf_swz(i * 16 + fr, s * 4 + fg)]);
+                    sc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][s], sc[i][0], 0, 0, 0);
+                    sc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][s], sc[i][1], 0, 0, 0);
+                }
+            }
+            // exponents of 2 relative to the reference; lane holds keys kv0 + 16i + 4fg + r of query fr
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4v kscale = float4v{kPfLog2e, kPfLog2e, kPfLog2e, kPfLog2e};
+                if constexpr (KV8) kscale = *reinterpret_cast<const float4v*>(&ldsS[buf][0][i * 16 + 4 * fg]) * kPfLog2e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool past = kv0 + i * 16 + 4 * fg + r >= T;
+                    sc[i][0][r] = past ? -1.0e30f : fmaf(sc[i][0][r], kscale[r], -mrun[0]);
+                    sc[i][1][r] = past ? -1.0e30f : fmaf(sc[i][1][r], kscale[r], -mrun[1]);
+                }
+            }
+            // ---- online softmax per query column
+            float mx[2];
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                float m = fmaxf(fmaxf(sc[0][qs][0], sc[0][qs][1]), fmaxf(sc[0][qs][2], sc[0][qs][3]));
+#pragma unroll
+                for (int i = 1; i < 4; ++i) m = fmaxf(m, fmaxf(fmaxf(sc[i][qs][0], sc[i][qs][1]), fmaxf(sc[i][qs][2], sc[i][qs][3])));
+                mx[qs] = pf_column_max(m);
+            }
+            if (it == 0 || __any(mx[0] > kPfRescaleGap || mx[1] > kPfRescaleGap)) {     // wave-uniform
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) {
+                    const float delta = it == 0 ? mx[qs] : fmaxf(mx[qs], 0.f);
+                    const float alpha = it == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                    mrun[qs] += delta;
+                    lrun[qs] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        o[i][qs][0] *= alpha; o[i][qs][1] *= alpha; o[i][qs][2] *= alpha; o[i][qs][3] *= alpha;
+                        sc[i][qs][0] -= delta; sc[i][qs][1] -= delta; sc[i][qs][2] -= delta; sc[i][qs][3] -= delta;
+                    }
+                }
+            }
+            half8 pf[2][2];            // [query tile][step of 32 keys]
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                float ps = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float4v vscale = float4v{1.f, 1.f, 1.f, 1.f};
+                    if constexpr (KV8) vscale = *reinterpret_cast<const float4v*>(&ldsS[buf][1][i * 16 + 4 * fg]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(sc[i][qs][r]);
+                        ps += pv;
+                        sc[i][qs][r] = KV8 ? pv * vscale[r] : pv;
+                    }
+                }
+                lrun[qs] += ps;                              // partial over this lane's keys; reduced at the end
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    pf[qs][s] = half8{(f16)sc[2 * s][qs][0], (f16)sc[2 * s][qs][1], (f16)sc[2 * s][qs][2], (f16)sc[2 * s][qs][3],
+                                      (f16)sc[2 * s + 1][qs][0], (f16)sc[2 * s + 1][qs][1], (f16)sc[2 * s + 1][qs][2],
+                                      (f16)sc[2 * s + 1][qs][3]};
+            }
+            // ---- O^T += V^T P^T; element j of step s is key 32s + 16(j>>2) + 4fg + (j&3)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f16* blk = &ldsV[buf][(32 * s + 4 * fg + (fr >> 2)) * PFVS + dt * 16 + 4 * (fr & 3)];
+                    typedef short short4v __attribute__((ext_vector_type(4)));
+                    typedef short short8v __attribute__((ext_vector_type(8)));
+                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)blk);
+                    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(blk + 16 * PFVS));
+                    const short8v both = short8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const half8 vf = __builtin_bit_cast(half8, both);
+                    o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0][s], o[dt][0], 0, 0, 0);
+                    o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][s], o[dt][1], 0, 0, 0);
+                }
+            }
+        }
+        if (it + 1 < ntile) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (!active) return;
+
+    // ---- normalise and store: lane holds O[query fr][16dt + 4fg .. +3]
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const float inv = 1.0f / pf_column_sum(lrun[qs]);
+        const int row = q0 + qs * 16 + fr;
+        if (row < P) {
+            f16* dst = out + ((long)seq * P + row) * D + h * 64 + 4 * fg;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<half4*>(dst + dt * 16) =
+                    half4{(f16)(o[dt][qs][0] * inv), (f16)(o[dt][qs][1] * inv), (f16)(o[dt][qs][2] * inv), (f16)(o[dt][qs][3] * inv)};
+        }
+    }
+}
+
 // dx[b][:] = x[b * P + P - 1][:] (the residual row of the last prompt position) and position = P - 1:
 // the state a step-by-step run would be in just before the final LayerNorm of its P-th step.
 // rep > 1 (beam search): every beam of recording b gets the row, and src_rows [Tctx][n_seq * rep] of the
@@ -2102,6 +2326,19 @@ void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out
                               int cache_seq_stride) {
     hipLaunchKernelGGL(prefill_self_attn_kernel, dim3(B * H, (P + 3) / 4), dim3(256), 0, s, qkv, kcache, vcache, out, H, P, Tctx, D,
                        cache_seq_stride);
+}
+
+void launch_prefill_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int P, int H, int T, int kv_rep,
+                               hipStream_t s) {
+    const float* none = nullptr;
+    hipLaunchKernelGGL(prefill_cross_attn_kernel<false>, dim3(B * H * ((P + PFQ - 1) / PFQ)), dim3(256), 0, s, q, kc, vc, none, none, out, H,
+                       P, T, kv_rep);
+}
+
+void launch_prefill_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
+                                int P, int H, int T, int kv_rep, hipStream_t s) {
+    hipLaunchKernelGGL(prefill_cross_attn_kernel<true>, dim3(B * H * ((P + PFQ - 1) / PFQ)), dim3(256), 0, s, q, k8, v8, ks, vs, out, H, P,
+                       T, kv_rep);
 }
 
 void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s, int rep, int* src_rows) {

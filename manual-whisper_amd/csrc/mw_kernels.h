@@ -172,7 +172,6 @@ void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out,
 void launch_dec_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
                             int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div = 1, int row0 = 0,
                             const int* done = nullptr, int done_div = 1, int stream_from = 1024);
-constexpr int kPrefillSlabRows = 256;      // query rows per cross-attention launch of the prompt prefill
 
 struct FinalizeParams {
     DecState* st;
@@ -195,6 +194,14 @@ void launch_prefill_embed(const int* forced, int n_forced, int B, int P, const f
 // cache_seq_stride: sequence b files its rows under cache sequence b * cache_seq_stride
 void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out, int B, int H, int P, int Tctx, int D, hipStream_t s,
                               int cache_seq_stride = 1);
+// Cross-attention of every prompt row: q, out [B*P][H*64] (rows m = sequence * P + position, q scaled); sequence b
+// attends over the cached encoder K/V ([recordings][H][T][64]) of recording b / kv_rep.  One pass of the keys per
+// (sequence, head, 128 prompt rows), on the matrix cores.
+void launch_prefill_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int P, int H, int T, int kv_rep,
+                               hipStream_t s);
+// The same over an e4m3 cache (codes k8, v8 and row scales ks, vs as for launch_dec_cross_attn8)
+void launch_prefill_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
+                                int P, int H, int T, int kv_rep, hipStream_t s);
 // dx [B*rep][D] = x rows of the last position, `rep` copies each; st->pos = P - 1; src_rows (beam search, else null):
 // int [Tctx][B*rep], its first P rows are pointed at the cache rows b * rep
 void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s, int rep = 1,

@@ -444,17 +444,20 @@ def test_batches_above_16_use_the_two_tile_kernels(name):
 # ---------------------------------------------------------------------------------------------
 # prompt prefill: all forced positions in one pass (the reference's initial_prompt makes the prompt long)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("weight_format", ["f16", "fp8"])
-@pytest.mark.parametrize("name,n_prompt,B", [("micro", 37, 5), ("tiny", 70, 3), ("micro", 2, 16), ("micro", 223, 2)])
+@pytest.mark.parametrize("weight_format", ["f16", "fp8", "fp8+kv8"])
+@pytest.mark.parametrize("name,n_prompt,B", [("micro", 37, 5), ("tiny", 70, 3), ("micro", 2, 16), ("micro", 223, 2), ("micro", 130, 4)])
 def test_prompt_prefill_matches_stepping_and_oracle(name, n_prompt, B, weight_format):
     """A long forced prompt (as `<|startofprev|> initial prompt ... <|notimestamps|>` is): the one-pass prefill gives
     the logits and ids of stepping through the prompt position by position, and both agree with the oracle.
-    Lengths: 2 (shortest prefilled), 37 / 70 (the reference's prompt is about this long), 223 (the longest prompt
-    Whisper allows: half the text context minus one)."""
+    Lengths: 2 (shortest prefilled), 37 / 70 (the reference's prompt is about this long), 130 (one prompt row past a
+    cross-attention block of 128 rows), 223 (the longest prompt Whisper allows: half the text context minus one).
+    "fp8+kv8": the cross-attention K/V cache in e4m3 as well (the prefill then reads codes and row scales)."""
     from manual_whisper_amd.engine import Engine
     dims = mw.get_dims(name)
     w = synth.make_weights_np(dims, 1234)
-    eng = Engine(dims, 0, 16, weight_format=weight_format)
+    kv_format = "fp8" if weight_format.endswith("+kv8") else "f16"
+    weight_format = weight_format.split("+")[0]
+    eng = Engine(dims, 0, 16, weight_format=weight_format, kv_format=kv_format)
     eng.load_weights(w)
     try:
         rng = np.random.default_rng(n_prompt)
@@ -469,7 +472,7 @@ def test_prompt_prefill_matches_stepping_and_oracle(name, n_prompt, B, weight_fo
         ids0, lens0, log0 = eng.decode_greedy(B, want_logits=True)
         eng.set_option("prefill", 1)
         ids1, lens1, log1 = eng.decode_greedy(B, want_logits=True)
-        orc = WhisperOracle(dims, w, weight_format=weight_format)
+        orc = WhisperOracle(dims, w, weight_format=weight_format, kv_format=kv_format)
         wi, wl, wlog = orc.greedy(enc, list(prompt), 8, opts.eot, opts.effective_suppress(), opts.begin_suppress, return_logits=True)
         n = wlog.shape[0]
         assert np.abs(log1[0] - wlog[0]).max() < LOGIT_ATOL            # first sampled position: straight out of the prefill
