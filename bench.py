@@ -42,10 +42,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, spec
 MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X dense fp16 MFMA, spec (no sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix (v_mfma_f32_32x32x2_f32: 256 FLOP/cycle/CU x 256 CUs x 2.4 GHz)
 # HBM bytes per launch of the cross-attention decode kernel at batch 16 from the PMC counters
-# (2 x FETCH_SIZE 60329.7 KB + WRITE_SIZE 530 KB, profiles/round2_pmc_counters_f16.csv); algorithmic bytes are 122.88 MB.
-XATTN_TRAFFIC_BYTES = 2 * 60329.7 * 1024 + 530.0 * 1024
-# the same at 112 sequences, the shape of a decode group (algorithmic 860.16 MB), profiles/round2_pmc_counters_f16_b112.csv
-XATTN_TRAFFIC_BYTES_112 = 2 * 420437.3 * 1024 + 280.0 * 1024        # cross_attn_stream_kernel, grid 573440
+# (2 x FETCH_SIZE 60330.3 KB + WRITE_SIZE 530 KB, profiles/round3_pmc_counters_f16.csv); algorithmic bytes are 122.88 MB.
+XATTN_TRAFFIC_BYTES = 2 * 60330.3 * 1024 + 530.0 * 1024
+# the same at 112 sequences, the shape of a decode group (algorithmic 860.16 MB), profiles/round3_pmc_counters_f16_b112.csv
+XATTN_TRAFFIC_BYTES_112 = 2 * 420411.9 * 1024 + 280.0 * 1024        # cross_attn_stream_kernel, grid 573440
 # the same for cross_attn8_kernel (e4m3 cache; algorithmic 65.28 MB), profiles/round1d_pmc_counters_fp8_kv8.csv
 XATTN8_TRAFFIC_BYTES = 2 * 32439.7 * 1024 + 530.0 * 1024
 BATCH = 16
@@ -654,7 +654,7 @@ def main(argv=None):
             "stage_roofline": stage_rooflines(dims, batch, len(opts.prompt), NEW_TOKENS, solo_ms, 1 if args.weights == "fp8" else 2, args.kv == "fp8"),
             "whole_run": None,
             "roofline": {"kernel": (("cross_attn_stream_kernel" if args.kv == "f16" else "cross_attn8_stream_kernel")
-                                    if (grouped and batch * args.group * dims.n_heads >= 1024) else
+                                    if ca_seqs * dims.n_heads >= 1024 else
                                     ("dec_attn_kernel<256,12,4>" if args.kv == "f16" else "cross_attn8_kernel<256,12,4>"))
                                    + " (decode cross-attention, one launch per layer per token)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -662,7 +662,7 @@ def main(argv=None):
                          "traffic": ((XATTN_TRAFFIC_BYTES if args.kv == "f16" else XATTN8_TRAFFIC_BYTES) if ca_seqs == 16 else
                                      XATTN_TRAFFIC_BYTES_112 if (ca_seqs == 112 and args.kv == "f16") else None),
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, profiles/"
-                                           + (("round2_pmc_counters_f16_b112.csv" if ca_seqs == 112 else "round2_pmc_counters_f16.csv") if args.kv == "f16" else "round1d_pmc_counters_fp8_kv8.csv"),
+                                           + (("round3_pmc_counters_f16_b112.csv" if ca_seqs == 112 else "round3_pmc_counters_f16.csv") if args.kv == "f16" else "round1d_pmc_counters_fp8_kv8.csv"),
                          "bytes_per_launch": ca_bytes, "avg_launch_us": round(ca_ms * 1e3, 2)},
         }
         if grouped:
