@@ -1780,11 +1780,19 @@ __device__ __forceinline__ float pf_column_sum(float v) {
     return v + __shfl_xor(v, 32);
 }
 
-template <bool KV8>
+// CAUSAL: the same kernel as the prompt's SELF-attention (modeling_whisper.py:473-478 for all prompt rows): q, k, v are the
+// three thirds of the rows of `q` ([sequences * P][3 * H * 64]: scaled q | k | v), key t is visible to query rows >= t,
+// key tiles past a workgroup's last row are never staged, and every workgroup files the k / v rows of its own 128 prompt
+// positions in the layer's cache (kcache / vcache [cache sequences][H][Tctx][64]; sequence b under cache sequence
+// b * cache_seq_stride), where the sampled positions will find them.
+template <bool KV8, bool CAUSAL = false>
 __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* __restrict__ q, const void* __restrict__ kc,
                                                                     const void* __restrict__ vc, const float* __restrict__ ks,
                                                                     const float* __restrict__ vs, f16* __restrict__ out, int H,
-                                                                    int P, int T, int kv_rep) {
+                                                                    int P, int T, int kv_rep, f16* __restrict__ kcache = nullptr,
+                                                                    f16* __restrict__ vcache = nullptr, int Tctx = 0,
+                                                                    int cache_seq_stride = 1) {
+    static_assert(!(KV8 && CAUSAL), "the self-attention cache is fp16");
     __shared__ __attribute__((aligned(16))) f16 ldsK[2][PFK * 64];
     __shared__ __attribute__((aligned(16))) f16 ldsV[2][PFK * PFVS];
     __shared__ __attribute__((aligned(16))) float ldsS[2][2][KV8 ? PFK : 4];
@@ -1797,14 +1805,27 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
     const int q0 = qblock * PFQ + wave * 32;
     const bool active = q0 < P;                 // wave-uniform
     const int D = H * 64;
-    const f16* qbase = q + (long)seq * P * D + h * 64;
+    const long ldq = CAUSAL ? 3L * D : D;
+    const f16* qbase = q + (long)seq * P * ldq + h * 64;
 
     half8 qf[2][2];
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
         const int row = min(q0 + qs * 16 + fr, P - 1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) qf[qs][s] = *reinterpret_cast<const half8*>(qbase + (long)row * D + s * 32 + fg * 8);
+        for (int s = 0; s < 2; ++s) qf[qs][s] = *reinterpret_cast<const half8*>(qbase + (long)row * ldq + s * 32 + fg * 8);
+    }
+    if constexpr (CAUSAL) {          // this block's k / v rows go to the cache: 128 rows x 8 pieces of 16 bytes, each of k and v
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = qblock * PFQ + (tid >> 3) + 32 * j;
+            if (row < P) {
+                const f16* src = qbase + (long)row * ldq + D + (tid & 7) * 8;
+                const long dst = (((long)seq * cache_seq_stride * H + h) * Tctx + row) * 64 + (tid & 7) * 8;
+                *reinterpret_cast<uint4*>(kcache + dst) = *reinterpret_cast<const uint4*>(src);
+                *reinterpret_cast<uint4*>(vcache + dst) = *reinterpret_cast<const uint4*>(src + D);
+            }
+        }
     }
 
     // staging: a thread moves two 8-element chunks of K and two of V per tile (16 bytes each, 8 in the e4m3 cache)
@@ -1817,7 +1838,11 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
         for (int i = 0; i < 2; ++i) {
             const int key = kv0 + (tid >> 3) + 32 * i;
             const long off = (bh_kv * T + key) * 64 + ch * 8;
-            if constexpr (KV8) {
+            if constexpr (CAUSAL) {
+                const f16* src = qbase + (long)key * ldq + D + ch * 8;
+                rk[i] = key < T ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+                rv[i] = key < T ? *reinterpret_cast<const uint4*>(src + D) : make_uint4(0, 0, 0, 0);
+            } else if constexpr (KV8) {
                 rk[i] = key < T ? *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(kc) + off) : make_uint2(0, 0);
                 rv[i] = key < T ? *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(vc) + off) : make_uint2(0, 0);
             } else {
@@ -1862,14 +1887,14 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
     float mrun[2] = {0.f, 0.f};
     float lrun[2] = {0.f, 0.f};
 
-    const int ntile = (T + PFK - 1) / PFK;
+    const int ntile = ((CAUSAL ? min(T, (qblock + 1) * PFQ) : T) + PFK - 1) / PFK;
     gload(0);
     lstore(0);
     __syncthreads();
     for (int it = 0; it < ntile; ++it) {
         const int buf = it & 1, kv0 = it * PFK;
         if (it + 1 < ntile) gload(kv0 + PFK);
-        if (active) {
+        if (active && !(CAUSAL && kv0 > q0 + 31)) {          // (wave-uniform) causal: tiles past the wave's last row hold nothing for it
             // ---- S^T tiles: [key tile i][query tile qs]
             float4v sc[4][2];
 #pragma unroll
@@ -1889,9 +1914,11 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
                 if constexpr (KV8) kscale = *reinterpret_cast<const float4v*>(&ldsS[buf][0][i * 16 + 4 * fg]) * kPfLog2e;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool past = kv0 + i * 16 + 4 * fg + r >= T;
-                    sc[i][0][r] = past ? -1.0e30f : fmaf(sc[i][0][r], kscale[r], -mrun[0]);
-                    sc[i][1][r] = past ? -1.0e30f : fmaf(sc[i][1][r], kscale[r], -mrun[1]);
+                    const int key = kv0 + i * 16 + 4 * fg + r;
+                    const bool past = key >= T;
+                    const bool hid0 = CAUSAL && key > q0 + fr, hid1 = CAUSAL && key > q0 + 16 + fr;
+                    sc[i][0][r] = (past || hid0) ? -1.0e30f : fmaf(sc[i][0][r], kscale[r], -mrun[0]);
+                    sc[i][1][r] = (past || hid1) ? -1.0e30f : fmaf(sc[i][1][r], kscale[r], -mrun[1]);
                 }
             }
             // ---- online softmax per query column
@@ -2324,8 +2351,16 @@ void launch_prefill_embed(const int* forced, int n_forced, int B, int P, const f
 
 void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out, int B, int H, int P, int Tctx, int D, hipStream_t s,
                               int cache_seq_stride) {
-    hipLaunchKernelGGL(prefill_self_attn_kernel, dim3(B * H, (P + 3) / 4), dim3(256), 0, s, qkv, kcache, vcache, out, H, P, Tctx, D,
-                       cache_seq_stride);
+    // a handful of positions: one wave per query; a real prompt: all rows of a (sequence, head) on the matrix cores
+    static const int mfma_from = getenv("MW_PREFILL_SELF_MFMA_FROM") ? atoi(getenv("MW_PREFILL_SELF_MFMA_FROM")) : 16;
+    if (P < mfma_from || D != H * 64) {
+        hipLaunchKernelGGL(prefill_self_attn_kernel, dim3(B * H, (P + 3) / 4), dim3(256), 0, s, qkv, kcache, vcache, out, H, P, Tctx, D,
+                           cache_seq_stride);
+        return;
+    }
+    const float* none = nullptr;
+    hipLaunchKernelGGL((prefill_cross_attn_kernel<false, true>), dim3(B * H * ((P + PFQ - 1) / PFQ)), dim3(256), 0, s, qkv,
+                       (const void*)nullptr, (const void*)nullptr, none, none, out, H, P, P, 1, kcache, vcache, Tctx, cache_seq_stride);
 }
 
 void launch_prefill_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int P, int H, int T, int kv_rep,
