@@ -265,7 +265,11 @@ int mw_profile_decode_gemvs(mw_ctx* ctx, int batch, int iters, float* mean_ms_pe
  * "xattn_stream_from" (number of (sequence, head) pairs from which the decode cross-attention runs as one
  * workgroup per pair that walks all 1500 keys, instead of four key ranges per pair merged by the last to finish:
  * large decode groups fill the GPU without the ranges and their hand-off costs bandwidth; default 1024,
- * 0 = never). */
+ * 0 = never),
+ * "xattn_stream_per_cu" (0..8: resident workgroups per compute unit that walking form is held to; 0 = what its
+ * registers allow, the default, and the fastest for an engine that has the GPU to itself.  With several engines on
+ * one GPU set 1: the stream keeps 97 % of its rate alone, and the short memory queues it leaves let the
+ * latency-bound launches of the other engines through: 149 -> 142 ms per step of the benchmark's arrangement). */
 int mw_set_option(mw_ctx* ctx, const char* key, int value);
 
 int mw_synchronize(mw_ctx* ctx);

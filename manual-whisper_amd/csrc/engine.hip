@@ -63,6 +63,7 @@ struct mw_ctx {
     bool finalized = false;
     int use_graph = 1, check_every = 4, use_prefill = 1, skip_done = 1;
     int xattn_stream_from = 1024;       // (sequence, head) pairs from which the decode cross-attention walks all keys per workgroup
+    int xattn_stream_per_cu = 0;        // resident workgroups per CU that form is held to (0: what its registers allow)
     bool can_end = true;                    // false when the decode options suppress end-of-text everywhere
     const mw_ctx* parent = nullptr;                       // non-null: weights and tables belong to `parent`
 
@@ -398,6 +399,7 @@ extern "C" int mw_fork_sized(mw_ctx* parent, int max_batch, mw_ctx** out) {
     ctx->d = parent->d; ctx->device = parent->device; ctx->max_batch = max_batch;
     ctx->use_graph = parent->use_graph; ctx->check_every = parent->check_every; ctx->use_prefill = parent->use_prefill;
     ctx->skip_done = parent->skip_done; ctx->xattn_stream_from = parent->xattn_stream_from;
+    ctx->xattn_stream_per_cu = parent->xattn_stream_per_cu;
     ctx->parent = parent; ctx->finalized = true;
     // shared, read-only on the hot path
     ctx->conv1_w = parent->conv1_w; ctx->conv1_b = parent->conv1_b; ctx->conv2_w = parent->conv2_w; ctx->conv2_b = parent->conv2_b;
@@ -445,6 +447,11 @@ extern "C" int mw_set_option(mw_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "skip_done")) {
         if (ctx->skip_done != (value != 0)) { int r = drop_graphs(ctx); if (r) return r; }
         ctx->skip_done = value != 0;
+    }
+    else if (!strcmp(key, "xattn_stream_per_cu")) {
+        if (value < 0 || value > 8) return fail(ctx, MW_ERR_ARG, "mw_set_option: xattn_stream_per_cu must be in 0..8");
+        if (ctx->xattn_stream_per_cu != value) { int r = drop_graphs(ctx); if (r) return r; }
+        ctx->xattn_stream_per_cu = value;
     }
     else if (!strcmp(key, "xattn_stream_from")) {
         if (ctx->xattn_stream_from != value) { int r = drop_graphs(ctx); if (r) return r; }
@@ -870,10 +877,10 @@ static void cross_attention(mw_ctx* ctx, int li, const f16* q, f16* out, int row
         const size_t per_layer_rows = (size_t)ctx->max_batch * d.n_audio_ctx * d.n_heads;
         launch_dec_cross_attn8(q, ctx->crossK8 + li * per_layer, ctx->crossV8 + li * per_layer, ctx->crossKs + li * per_layer_rows,
                                ctx->crossVs + li * per_layer_rows, out, rows, d.n_heads, d.n_audio_ctx, ctx->xpartial, ctx->xtickets,
-                               ctx->stream, kv_div, row0, done, done_div, ctx->xattn_stream_from);
+                               ctx->stream, kv_div, row0, done, done_div, ctx->xattn_stream_from, ctx->xattn_stream_per_cu);
     } else {
         launch_dec_cross_attn(q, ctx->crossK + li * per_layer, ctx->crossV + li * per_layer, out, rows, d.n_heads, d.n_audio_ctx,
-                              ctx->xpartial, ctx->xtickets, ctx->stream, kv_div, row0, done, done_div, ctx->xattn_stream_from);
+                              ctx->xpartial, ctx->xtickets, ctx->stream, kv_div, row0, done, done_div, ctx->xattn_stream_from, ctx->xattn_stream_per_cu);
     }
 }
 

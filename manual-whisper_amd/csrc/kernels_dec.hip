@@ -2309,8 +2309,12 @@ void launch_dec_self_attn(const f16* q, const f16* kc, const f16* vc, f16* out, 
     }
 }
 
+// LDS request that holds a kernel without LDS needs of its own to `per_cu` workgroups per CU (160 KiB of LDS per CU)
+static size_t lds_request_for(int per_cu) { return per_cu <= 0 ? 0 : per_cu == 1 ? 96 * 1024 : (size_t)(160 * 1024 / (per_cu + 1) + 1024); }
+
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
-                           int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div, int stream_from_arg) {
+                           int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div, int stream_from_arg,
+                           int stream_per_cu) {
     // 4 key ranges of 375 frames per (sequence, head); 256 threads = 32 row groups x 12 rows = 384 >= 375
     const dim3 g1(B * H * kXattnSplit), g2(H * kXattnSplit, B);
     const DecState* nost = nullptr;
@@ -2325,10 +2329,11 @@ void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out,
     // ranges and no ticket hand-off (cross_attn_stream_kernel); three workgroups per CU as above.
     static const int stream_from_env = getenv("MW_XSTREAM_FROM") ? atoi(getenv("MW_XSTREAM_FROM")) : -1;     // A/B runs
     const int stream_from = stream_from_env >= 0 ? stream_from_env : stream_from_arg;
-    static const int stream_lds = getenv("MW_XSTREAM_LDS") ? atoi(getenv("MW_XSTREAM_LDS")) : 0;    // 150 registers: three per CU as it is
+    static const int stream_lds_env = getenv("MW_XSTREAM_LDS") ? atoi(getenv("MW_XSTREAM_LDS")) : -1;      // A/B runs
+    const size_t stream_lds = stream_lds_env >= 0 ? (size_t)stream_lds_env : lds_request_for(stream_per_cu);
     if (kv_div == 1 && stream_from > 0 && (long)B * H >= stream_from) {
-        if (done) hipLaunchKernelGGL(cross_attn_stream_kernel<true>, dim3(H, B), dim3(256), (size_t)stream_lds, s, q, kc, vc, out, H, T, done, done_div);
-        else hipLaunchKernelGGL(cross_attn_stream_kernel<false>, dim3(B * H), dim3(256), (size_t)stream_lds, s, q, kc, vc, out, H, T, done, done_div);
+        if (done) hipLaunchKernelGGL(cross_attn_stream_kernel<true>, dim3(H, B), dim3(256), stream_lds, s, q, kc, vc, out, H, T, done, done_div);
+        else hipLaunchKernelGGL(cross_attn_stream_kernel<false>, dim3(B * H), dim3(256), stream_lds, s, q, kc, vc, out, H, T, done, done_div);
         return;
     }
     if (kv_div > 1) {
@@ -2382,13 +2387,15 @@ void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, De
 
 void launch_dec_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
                             int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div, int row0, const int* done, int done_div,
-                            int stream_from_arg) {
+                            int stream_from_arg, int stream_per_cu) {
     // decode groups: one workgroup per (sequence, head) walking all keys, as launch_dec_cross_attn
     static const int stream_from_env = getenv("MW_XSTREAM_FROM") ? atoi(getenv("MW_XSTREAM_FROM")) : -1;
     const int stream_from = stream_from_env >= 0 ? stream_from_env : stream_from_arg;
+    static const int stream_lds_env = getenv("MW_XSTREAM_LDS") ? atoi(getenv("MW_XSTREAM_LDS")) : -1;      // A/B runs
+    const size_t stream_lds = stream_lds_env >= 0 ? (size_t)stream_lds_env : lds_request_for(stream_per_cu);
     if (kv_div == 1 && stream_from > 0 && (long)B * H >= stream_from) {
-        if (done) hipLaunchKernelGGL(cross_attn8_stream_kernel<true>, dim3(H, B), dim3(256), 0, s, q, k8, v8, ks, vs, out, H, T, done, done_div);
-        else hipLaunchKernelGGL(cross_attn8_stream_kernel<false>, dim3(B * H), dim3(256), 0, s, q, k8, v8, ks, vs, out, H, T, done, done_div);
+        if (done) hipLaunchKernelGGL(cross_attn8_stream_kernel<true>, dim3(H, B), dim3(256), stream_lds, s, q, k8, v8, ks, vs, out, H, T, done, done_div);
+        else hipLaunchKernelGGL(cross_attn8_stream_kernel<false>, dim3(B * H), dim3(256), stream_lds, s, q, k8, v8, ks, vs, out, H, T, done, done_div);
         return;
     }
     // 4 key ranges of 375 frames; 256 threads = 32 row groups x 12 rows = 384 >= 375

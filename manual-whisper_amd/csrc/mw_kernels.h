@@ -165,13 +165,16 @@ constexpr int kXattnSplit = 4;
 // that have ended, recordings whose beam search is complete.
 // stream_from: from this many (sequence, head) pairs on (and kv_div == 1) one workgroup per pair walks all the keys
 // (cross_attn_stream_kernel) instead of four key ranges per pair merged through tickets; <= 0: never.
+// stream_per_cu: resident workgroups per CU that form is held to (by an LDS request nothing uses): 0 = what its
+// registers allow (three).  One per CU streams within 2 - 3 % of three (its loads in flight still cover the HBM round
+// trip) and leaves the memory queues short for the latency-bound launches of other streams.
 void launch_dec_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int H, int T, float* partial,
                            int* tickets, hipStream_t s, int kv_div = 1, int row0 = 0, const int* done = nullptr, int done_div = 1,
-                           int stream_from = 1024);
+                           int stream_from = 1024, int stream_per_cu = 0);
 // The same over an e4m3 cache: k8, v8 [B][H][T][64] codes, ks, vs [B][H][T] row scales
 void launch_dec_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
                             int H, int T, float* partial, int* tickets, hipStream_t s, int kv_div = 1, int row0 = 0,
-                            const int* done = nullptr, int done_div = 1, int stream_from = 1024);
+                            const int* done = nullptr, int done_div = 1, int stream_from = 1024, int stream_per_cu = 0);
 
 struct FinalizeParams {
     DecState* st;

@@ -58,6 +58,9 @@ class EnginePool:
             raise ValueError("temperature fallback needs detokenize")
         _lib.check_hw_queues(n_engines)              # one stream per engine
         self.engines = [engine] + [engine.fork() for _ in range(n_engines - 1)]
+        if n_engines > 1:       # engines that share the GPU: see GroupedPool
+            for e in self.engines:
+                e.set_option("xattn_stream_per_cu", int(os.environ.get("MW_XSTREAM_PER_CU", "1")))
         self._free: "queue.Queue" = queue.Queue()
         for e in self.engines:
             self._free.put(e)
@@ -125,6 +128,11 @@ class GroupedPool:
         _lib.check_hw_queues(n_encoders + n_decoders + (0 if first else 1))       # one stream per engine, the root's included
         self.encoders = first + [engine.fork(batch) for _ in range(n_encoders - len(first))]
         self.decoders = [engine.fork(batch * group) for _ in range(n_decoders)]
+        # engines that share the GPU: one resident workgroup per CU for the decode cross-attention stream of a group
+        # (mw_set_option "xattn_stream_per_cu"); MW_XSTREAM_PER_CU overrides (0 = as many as the registers allow)
+        per_cu = int(os.environ.get("MW_XSTREAM_PER_CU", "1"))
+        for e in self.decoders:
+            e.set_option("xattn_stream_per_cu", per_cu)
         self._enc_pool = ThreadPoolExecutor(max_workers=n_encoders)
         self._dec_pool = ThreadPoolExecutor(max_workers=n_decoders)
         self._free_enc: "queue.Queue" = queue.Queue()

@@ -64,6 +64,9 @@ class _StandInEngine:
     def set_decode_options(self, opts):
         pass
 
+    def set_option(self, key, value):
+        self.log.append(("option", key, value))
+
     def encode_into(self, pcm, dst, slot0):
         assert pcm.shape[0] <= self.max_batch
         for r in range(pcm.shape[0]):
