@@ -315,7 +315,7 @@ def prompt75_run(eng, dims, opts, dev, batch, args):
             "value": round(steps * batch * 30.0 / dt, 2), "unit": "audio-seconds/second", "ms_per_step": round(dt / steps * 1e3, 3)}
 
 
-def beam5_run(dims, opts, dev, local_rank, weights="f16", kv="f16", n_rec=25, engines=2, passes=3):
+def beam5_run(dims, opts, dev, local_rank, weights="f16", kv="f16", n_rec=25, engines=3, passes=3):
     """whisperx decodes with a beam of 5 unless told otherwise, and the reference overrides only initial_prompt
     (transcribe.py:111): the same chunks through mw_decode_beam, `n_rec` recordings (x 5 hypotheses) per pass."""
     import torch

@@ -873,6 +873,23 @@ static void cross_attention(mw_ctx* ctx, int li, const f16* q, f16* out, int row
                             const int* done = nullptr, int done_div = 1) {
     const mw_model_desc& d = ctx->d;
     const size_t per_layer = (size_t)ctx->max_batch * d.n_audio_ctx * d.d_model;
+    // Several hypotheses per recording (beam search, best-of-n samples): the rows of a recording share its K/V, so one
+    // workgroup per (recording, head) reads them ONCE for all of them (the prompt prefill's kernel; the single-query
+    // kernel reads them once per hypothesis).  MW_SHARED_XATTN=0: the single-query kernel.
+    static const bool shared_off = getenv("MW_SHARED_XATTN") && atoi(getenv("MW_SHARED_XATTN")) == 0;
+    if (!shared_off && kv_div > 1 && row0 == 0 && rows % kv_div == 0) {
+        const int n_rec = rows / kv_div;
+        if (ctx->kv8) {
+            const size_t per_layer_rows = (size_t)ctx->max_batch * d.n_audio_ctx * d.n_heads;
+            launch_prefill_cross_attn8(q, ctx->crossK8 + li * per_layer, ctx->crossV8 + li * per_layer, ctx->crossKs + li * per_layer_rows,
+                                       ctx->crossVs + li * per_layer_rows, out, n_rec, kv_div, d.n_heads, d.n_audio_ctx, 1, ctx->stream, done,
+                                       done_div);
+        } else {
+            launch_prefill_cross_attn(q, ctx->crossK + li * per_layer, ctx->crossV + li * per_layer, out, n_rec, kv_div, d.n_heads,
+                                      d.n_audio_ctx, 1, ctx->stream, done, done_div);
+        }
+        return;
+    }
     if (ctx->kv8) {
         const size_t per_layer_rows = (size_t)ctx->max_batch * d.n_audio_ctx * d.n_heads;
         launch_dec_cross_attn8(q, ctx->crossK8 + li * per_layer, ctx->crossV8 + li * per_layer, ctx->crossKs + li * per_layer_rows,

@@ -1791,7 +1791,8 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
                                                                     const float* __restrict__ vs, f16* __restrict__ out, int H,
                                                                     int P, int T, int kv_rep, f16* __restrict__ kcache = nullptr,
                                                                     f16* __restrict__ vcache = nullptr, int Tctx = 0,
-                                                                    int cache_seq_stride = 1) {
+                                                                    int cache_seq_stride = 1, const int* __restrict__ done = nullptr,
+                                                                    int done_div = 1) {
     static_assert(!(KV8 && CAUSAL), "the self-attention cache is fp16");
     __shared__ __attribute__((aligned(16))) f16 ldsK[2][PFK * 64];
     __shared__ __attribute__((aligned(16))) f16 ldsV[2][PFK * PFVS];
@@ -1801,6 +1802,12 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
     const int nqb = (P + PFQ - 1) / PFQ;
     const int bh = blockIdx.x / nqb, qblock = blockIdx.x - bh * nqb;
     const int seq = bh / H, h = bh - seq * H;
+    if (done) {      // rows r with done[r / done_div] set keep what `out` held: a workgroup all of whose rows are done has no work
+        bool all_done = true;
+        for (int r = seq * P + qblock * PFQ; r < min(seq * P + P, seq * P + (qblock + 1) * PFQ) && all_done; ++r)
+            all_done = done[r / done_div] != 0;
+        if (all_done) return;                   // (workgroup-uniform, before any barrier)
+    }
     const long bh_kv = (long)(seq / kv_rep) * H + h;
     const int q0 = qblock * PFQ + wave * 32;
     const bool active = q0 < P;                 // wave-uniform
@@ -2369,16 +2376,18 @@ void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out
 }
 
 void launch_prefill_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int P, int H, int T, int kv_rep,
-                               hipStream_t s) {
+                               hipStream_t s, const int* done, int done_div) {
     const float* none = nullptr;
+    f16* nocache = nullptr;
     hipLaunchKernelGGL(prefill_cross_attn_kernel<false>, dim3(B * H * ((P + PFQ - 1) / PFQ)), dim3(256), 0, s, q, kc, vc, none, none, out, H,
-                       P, T, kv_rep);
+                       P, T, kv_rep, nocache, nocache, 0, 1, done, done_div);
 }
 
 void launch_prefill_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
-                                int P, int H, int T, int kv_rep, hipStream_t s) {
+                                int P, int H, int T, int kv_rep, hipStream_t s, const int* done, int done_div) {
+    f16* nocache = nullptr;
     hipLaunchKernelGGL(prefill_cross_attn_kernel<true>, dim3(B * H * ((P + PFQ - 1) / PFQ)), dim3(256), 0, s, q, k8, v8, ks, vs, out, H, P,
-                       T, kv_rep);
+                       T, kv_rep, nocache, nocache, 0, 1, done, done_div);
 }
 
 void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s, int rep, int* src_rows) {

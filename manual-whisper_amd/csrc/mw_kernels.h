@@ -199,12 +199,14 @@ void launch_prefill_self_attn(const f16* qkv, f16* kcache, f16* vcache, f16* out
                               int cache_seq_stride = 1);
 // Cross-attention of every prompt row: q, out [B*P][H*64] (rows m = sequence * P + position, q scaled); sequence b
 // attends over the cached encoder K/V ([recordings][H][T][64]) of recording b / kv_rep.  One pass of the keys per
-// (sequence, head, 128 prompt rows), on the matrix cores.
+// (sequence, head, 128 prompt rows), on the matrix cores.  Also the decode step of beam search and of best-of-n
+// sampling: B recordings with P hypotheses each are B "sequences" of P rows that share one K/V cache.
+// done != null: a workgroup all of whose rows r have done[r / done_div] != 0 does nothing (`out` keeps what it held).
 void launch_prefill_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* out, int B, int P, int H, int T, int kv_rep,
-                               hipStream_t s);
+                               hipStream_t s, const int* done = nullptr, int done_div = 1);
 // The same over an e4m3 cache (codes k8, v8 and row scales ks, vs as for launch_dec_cross_attn8)
 void launch_prefill_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
-                                int P, int H, int T, int kv_rep, hipStream_t s);
+                                int P, int H, int T, int kv_rep, hipStream_t s, const int* done = nullptr, int done_div = 1);
 // dx [B*rep][D] = x rows of the last position, `rep` copies each; st->pos = P - 1; src_rows (beam search, else null):
 // int [Tctx][B*rep], its first P rows are pointed at the cache rows b * rep
 void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s, int rep = 1,

@@ -253,7 +253,7 @@ class Model:
 
 def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, compute_type: str = "float16",
                asr_options: Optional[dict] = None, language: Optional[str] = None, vad_options: Optional[dict] = None,
-               task: str = "transcribe", max_batch: Optional[int] = None, n_engines: int = 2, coalesce: int = 4,
+               task: str = "transcribe", max_batch: Optional[int] = None, n_engines: Optional[int] = None, coalesce: int = 4,
                arrangement: str = "grouped", group: int = 7, n_encoders: int = 2, n_decoders: int = 3,
                **_ignored) -> Model:
     """Build an engine on GPU ``device_index``.
@@ -266,10 +266,13 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
     the greedy loop over up to ``group`` such batches at once, so the decoder weights stream once per token per
     group; the engines are created at the first call, sized to the recording (a decode engine takes about 0.32 GB
     per chunk at large-v3).  ``arrangement="coalesced"`` (always used for beam search): ``n_engines`` engines in
-    flight that each run whole passes of ``coalesce`` batches, ``max_batch`` chunks at most (default 16 * coalesce).
+    flight (default 2; 3 for beam search) that each run whole passes of ``coalesce`` batches, ``max_batch`` chunks at
+    most (default 16 * coalesce).
     """
     coalesce = max(1, int(coalesce))
     beam = int((asr_options or {}).get("beam_size", 1))
+    if n_engines is None:       # measured (tools/beam_probe.py): beam 5 on passes of 25 recordings, 2 engines 1577 audio-s/s, 3 engines 1752
+        n_engines = 3 if beam > 1 else 2
     from .fallback import FallbackOptions
     fallback = FallbackOptions.from_asr_options(asr_options or {})
     if max_batch is None:
