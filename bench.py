@@ -342,6 +342,22 @@ def beam5_run(dims, opts, dev, local_rank, weights="f16", kv="f16", n_rec=25, en
             "value": round(engines * passes * n_rec * 30.0 / dt, 2), "unit": "audio-seconds/second", "ms_per_pass": round(dt / (engines * passes) * 1e3, 2)}
 
 
+def e2e_in_child(local_rank, tokens):
+    """e2e_run in a process of its own, as `python transcribe.py recording` is.  In THIS process the engines of the
+    measurements above have come and gone around a root engine that is still alive, and a second model built in that
+    state runs its decode loops 20 % slower on this runtime (tools/e2e_probe.py with E2E_CHURN=1..7: 3.1 s against
+    2.4 s for the hour; every kernel alone as fast, encoder passes as fast)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--e2e-child", str(local_rank), str(tokens)]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    for line in reversed(res.stdout.splitlines()):
+        if line.startswith("{"):
+            out = json.loads(line)
+            out["process"] = "a fresh process (as the reference's one run per recording)"
+            return out
+    return {"error": "the child process printed no result", "returncode": res.returncode, "stderr_tail": res.stderr[-400:]}
+
+
 def e2e_run(local_rank, minutes=60, tokens=128):
     """The reference's call shape end to end (transcribe.py:107-135): load_model with its VAD_OPTIONS, model.transcribe on
     a host buffer holding a 60-minute recording (speech windows -> chunks -> passes -> segments), then forced alignment of
@@ -471,6 +487,9 @@ def launch_ranks(n_gpus: int, argv) -> int:
 
 
 def main(argv=None):
+    if argv is None and len(sys.argv) >= 4 and sys.argv[1] == "--e2e-child":
+        print(json.dumps(e2e_run(int(sys.argv[2]), tokens=int(sys.argv[3]))), flush=True)
+        return
     global NEW_TOKENS
     argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
@@ -731,7 +750,7 @@ def main(argv=None):
         if world == 1 and not args.no_beam5 and args.model == MODEL and args.weights == "f16":
             out["beam5"] = beam5_run(dims, opts, dev, local_rank)
         if world == 1 and not args.no_e2e and args.model == MODEL and args.weights == "f16":
-            out["e2e"] = e2e_run(local_rank, tokens=NEW_TOKENS)
+            out["e2e"] = e2e_in_child(local_rank, NEW_TOKENS)
         if weights_np is not None:
             def gpu_ids(pcm, n_new):
                 o = synthetic_options(dims, max_new=n_new, suppress_eot=True)
