@@ -650,7 +650,7 @@ def main(argv=None):
         ca_ms, ca_bytes = pool.decoders[0].profile_cross_attention(ca_seqs, iters=128)
         # the pool holds the kernel to one resident workgroup per CU (what the timed region runs: the figure above);
         # beside it, the same launches with as many as the registers allow (the fastest form for an engine alone)
-        per_cu = int(os.environ.get("MW_XSTREAM_PER_CU", "1"))
+        per_cu = int(os.environ.get("MW_XSTREAM_PER_CU", "1" if args.decoders > 1 else "0"))
         pool.decoders[0].set_option("xattn_stream_per_cu", 0)
         ca_free_ms, _ = pool.decoders[0].profile_cross_attention(ca_seqs, iters=128)
         pool.decoders[0].set_option("xattn_stream_per_cu", per_cu)

@@ -130,7 +130,8 @@ class GroupedPool:
         self.decoders = [engine.fork(batch * group) for _ in range(n_decoders)]
         # engines that share the GPU: one resident workgroup per CU for the decode cross-attention stream of a group
         # (mw_set_option "xattn_stream_per_cu"); MW_XSTREAM_PER_CU overrides (0 = as many as the registers allow)
-        per_cu = int(os.environ.get("MW_XSTREAM_PER_CU", "1"))
+        # (a lone decode engine keeps the faster form: only the encoders run beside it, and not for long)
+        per_cu = int(os.environ.get("MW_XSTREAM_PER_CU", "1" if n_decoders > 1 else "0"))
         for e in self.decoders:
             e.set_option("xattn_stream_per_cu", per_cu)
         self._enc_pool = ThreadPoolExecutor(max_workers=n_encoders)
