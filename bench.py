@@ -736,7 +736,7 @@ def main(argv=None):
         torch.cuda.empty_cache()
         # Order: first what runs on this run's root engine (pools rebuilt on the same root, the CPU baseline's id checks), then
         # the root is closed, then the measurements that load models of their own: a model whose root engine is created
-        # beside an older root that has had forks decodes 20 % slower on this runtime.
+        # beside an older root that has had forks decodes 20 % slower on this runtime (tools/e2e_probe.py, E2E_CHURN).
         if world == 1 and grouped and not args.no_rank_share and args.model == MODEL and args.weights == "f16":
             out["rank_share"] = rank_share_run(eng, dims, opts, dev, batch)
         if world == 1 and grouped and not args.no_prompt75 and args.model == MODEL:
