@@ -315,18 +315,21 @@ def prompt75_run(eng, dims, opts, dev, batch, args):
             "value": round(steps * batch * 30.0 / dt, 2), "unit": "audio-seconds/second", "ms_per_step": round(dt / steps * 1e3, 3)}
 
 
-def beam5_run(dims, opts, dev, local_rank, weights="f16", kv="f16", n_rec=25, engines=3, passes=3):
+def beam5_run(dims, opts, dev, local_rank, weights="f16", kv="f16", n_rec=48, engines=3, passes=3):
     """whisperx decodes with a beam of 5 unless told otherwise, and the reference overrides only initial_prompt
-    (transcribe.py:111): the same chunks through mw_decode_beam, `n_rec` recordings (x 5 hypotheses) per pass."""
+    (transcribe.py:111): the same chunks through mw_decode_beam, `n_rec` recordings (x 5 hypotheses) per pass, on the
+    engines load_model(asr_options={"beam_size": 5}) builds: forks for n_rec * 5 sequences whose cross-attention K/V
+    cache holds the n_rec recordings once."""
     import torch
     from manual_whisper_amd import synth
     from manual_whisper_amd.engine import Engine
     from manual_whisper_amd.scheduler import EnginePool
     beam = 5
-    eng = Engine(dims, device=local_rank, max_batch=n_rec * beam, weight_format=weights, kv_format=kv)
+    eng = Engine(dims, device=local_rank, max_batch=16, weight_format=weights, kv_format=kv)
     eng.load_weights(synth.make_weights_torch(dims, seed=1234, device=dev))
     eng.set_decode_options(opts)
-    pool = EnginePool(eng, engines, beam_size=beam)
+    pool = EnginePool(eng, engines, beam_size=beam, fork_batch=n_rec * beam, fork_cache=n_rec)
+    pool.set_decode_options(opts)
     pcms = [synth.make_pcm_torch(n_rec, seed=6000 + i, device=dev) for i in range(2)]
     torch.cuda.synchronize()
     pool.map([pcms[i % 2] for i in range(engines)])

@@ -120,6 +120,13 @@ int mw_fork(mw_ctx* parent, mw_ctx** out);
  * what they encoded (mw_encode_into). */
 int mw_fork_sized(mw_ctx* parent, int max_batch, mw_ctx** out);
 
+/* mw_fork_sized with a cross-attention K/V cache for `cache_sequences` <= max_batch sequences only.  The hypotheses of
+ * a recording (mw_decode_beam, mw_decode_sample) share the recording's cache, so an engine that decodes n recordings
+ * with b hypotheses each needs max_batch = n * b but a cache of n: at large-v3 a cached sequence is 0.25 GB.  Encoder
+ * passes, greedy and teacher-forced decoding on such a context take at most cache_sequences chunks.  Behind whisperx's
+ * default decoding (beam 5; reference transcribe.py:107-113,123). */
+int mw_fork_cached(mw_ctx* parent, int max_batch, int cache_sequences, mw_ctx** out);
+
 /* Free everything the context owns (reference transcribe.py:153-154 `del model`). */
 void mw_destroy(mw_ctx* ctx);
 

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MW_LIB_PATH") or os.path.join(_HERE, "libmwhip.so")  
 
 # every symbol include/mwhip.h declares
 SYMBOLS = (
-    "mw_create", "mw_fork", "mw_fork_sized", "mw_set_weight", "mw_finalize", "mw_set_decode_opts", "mw_destroy", "mw_last_error",
+    "mw_create", "mw_fork", "mw_fork_sized", "mw_fork_cached", "mw_set_weight", "mw_finalize", "mw_set_decode_opts", "mw_destroy", "mw_last_error",
     "mw_logmel", "mw_logmel_noalloc", "mw_encode", "mw_encode_into", "mw_set_encoded", "mw_read_cross_kv", "mw_decode_greedy", "mw_decode_beam", "mw_decode_sample", "mw_sample_uniform", "mw_decode_forced", "mw_transcribe_batch",
     "mw_frame_energy_db", "mw_stage_ms", "mw_profile_cross_attention", "mw_profile_decode_gemvs", "mw_set_option", "mw_synchronize",
     "mw_align_frames", "mw_align_create", "mw_align_destroy", "mw_align_last_error", "mw_align_set_weight", "mw_align_finalize",
@@ -139,6 +139,7 @@ def load() -> C.CDLL:
     lib.mw_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.c_int, C.POINTER(vp)]
     lib.mw_fork.argtypes = [vp, C.POINTER(vp)]
     lib.mw_fork_sized.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    lib.mw_fork_cached.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.mw_encode_into.argtypes = [vp, f32p, C.c_int, vp, C.c_int]
     lib.mw_set_encoded.argtypes = [vp, C.c_int]
     lib.mw_read_cross_kv.argtypes = [vp, C.c_int, C.c_int, f32p, f32p]

@@ -57,6 +57,7 @@ struct DecLayerW { NormW ln1, ln2, ln3; LinearW qkv, out, cq, co, fc1, fc2; };
 struct mw_ctx {
     mw_model_desc d{};
     int device = 0, max_batch = 0;
+    int cache_seqs = 0;                 // sequences the cross-attention K/V cache holds (<= max_batch; hypotheses of a recording share one)
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<void*> allocs;
@@ -316,7 +317,7 @@ static int alloc_weights(mw_ctx* ctx) {
 static int alloc_work(mw_ctx* ctx) {
     const mw_model_desc& d = ctx->d;
     const size_t D = d.d_model, F = d.ffn_dim, H = d.n_heads, T = d.n_audio_ctx, B = ctx->max_batch;
-    const size_t M = B * T;
+    const size_t M = B * T, MC = (size_t)ctx->cache_seqs * T;
     ctx->Tpad = (int)((T + 7) / 8 * 8);
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->fin_host), 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         ctx->err = "hipHostMalloc failed"; return MW_ERR_HIP;
@@ -336,11 +337,11 @@ static int alloc_work(mw_ctx* ctx) {
     ALLOC(ctx->att, M * D); ALLOC(ctx->hid, M * F);
     ALLOC(ctx->enc_out, M * D); ALLOC(ctx->enc_out32, M * D);
     if (ctx->kv8) {
-        ALLOC(ctx->crossK8, (size_t)d.dec_layers * M * D); ALLOC(ctx->crossV8, (size_t)d.dec_layers * M * D);
-        ALLOC(ctx->crossKs, (size_t)d.dec_layers * M * H); ALLOC(ctx->crossVs, (size_t)d.dec_layers * M * H);
+        ALLOC(ctx->crossK8, (size_t)d.dec_layers * MC * D); ALLOC(ctx->crossV8, (size_t)d.dec_layers * MC * D);
+        ALLOC(ctx->crossKs, (size_t)d.dec_layers * MC * H); ALLOC(ctx->crossVs, (size_t)d.dec_layers * MC * H);
     } else {
-        ALLOC(ctx->crossK, (size_t)d.dec_layers * M * D);
-        ALLOC(ctx->crossV, (size_t)d.dec_layers * M * D);
+        ALLOC(ctx->crossK, (size_t)d.dec_layers * MC * D);
+        ALLOC(ctx->crossV, (size_t)d.dec_layers * MC * D);
     }
     // decoder workspaces
     ALLOC(ctx->st, 1, true);
@@ -381,7 +382,7 @@ extern "C" int mw_create(const mw_model_desc* desc, int device, int max_batch, m
         return MW_ERR_HIP;
     }
     mw_ctx* ctx = new mw_ctx();
-    ctx->d = d; ctx->device = device; ctx->max_batch = max_batch;
+    ctx->d = d; ctx->device = device; ctx->max_batch = max_batch; ctx->cache_seqs = max_batch;
     ctx->fp8 = d.weight_format == MW_WEIGHTS_FP8;
     ctx->kv8 = d.kv_format == MW_KV_FP8;
     auto bail = [&](int code) { g_create_error = ctx->err; mw_destroy(ctx); return code; };
@@ -423,14 +424,17 @@ extern "C" void mw_destroy(mw_ctx* ctx) {
 
 extern "C" int mw_fork(mw_ctx* parent, mw_ctx** out) { return mw_fork_sized(parent, parent ? parent->max_batch : 0, out); }
 
-extern "C" int mw_fork_sized(mw_ctx* parent, int max_batch, mw_ctx** out) {
+extern "C" int mw_fork_sized(mw_ctx* parent, int max_batch, mw_ctx** out) { return mw_fork_cached(parent, max_batch, max_batch, out); }
+
+extern "C" int mw_fork_cached(mw_ctx* parent, int max_batch, int cache_sequences, mw_ctx** out) {
     if (!parent || !out) return MW_ERR_ARG;
     *out = nullptr;
     if (!parent->finalized) return fail(parent, MW_ERR_STATE, "mw_fork: the parent must be finalized first");
     if (parent->parent) return fail(parent, MW_ERR_ARG, "mw_fork: fork from the original engine, not from a fork");
     if (max_batch < 1 || max_batch > kMaxBatch) return fail(parent, MW_ERR_ARG, "mw_fork_sized: max_batch must be in 1..512");
+    if (cache_sequences < 1 || cache_sequences > max_batch) return fail(parent, MW_ERR_ARG, "mw_fork_cached: cache_sequences must be in 1..max_batch");
     mw_ctx* ctx = new mw_ctx();
-    ctx->d = parent->d; ctx->device = parent->device; ctx->max_batch = max_batch;
+    ctx->d = parent->d; ctx->device = parent->device; ctx->max_batch = max_batch; ctx->cache_seqs = cache_sequences;
     ctx->use_graph = parent->use_graph; ctx->check_every = parent->check_every; ctx->use_prefill = parent->use_prefill;
     ctx->skip_done = parent->skip_done; ctx->xattn_stream_from = parent->xattn_stream_from;
     ctx->xattn_stream_per_cu = parent->xattn_stream_per_cu;
@@ -701,9 +705,11 @@ extern "C" int mw_set_decode_opts(mw_ctx* ctx, const mw_decode_opts* o) {
 // ---------------------------------------------------------------------------------------------
 // hot path
 // ---------------------------------------------------------------------------------------------
-static int check_batch(mw_ctx* ctx, int batch, const char* who) {
+// cached: every sequence of the batch has a slot of its own in the cross-attention K/V cache (encoder passes, greedy decoding)
+static int check_batch(mw_ctx* ctx, int batch, const char* who, bool cached = true) {
     if (!ctx->finalized) return fail(ctx, MW_ERR_STATE, std::string(who) + ": mw_finalize has not succeeded yet");
-    if (batch < 1 || batch > ctx->max_batch) return fail(ctx, MW_ERR_ARG, std::string(who) + ": batch must be in 1.." + std::to_string(ctx->max_batch));
+    const int limit = cached ? ctx->cache_seqs : ctx->max_batch;
+    if (batch < 1 || batch > limit) return fail(ctx, MW_ERR_ARG, std::string(who) + ": batch must be in 1.." + std::to_string(limit));
     return MW_OK;
 }
 
@@ -718,7 +724,7 @@ static int run_logmel(mw_ctx* ctx, const float* pcm_dev, int B) {
 
 extern "C" int mw_logmel(mw_ctx* ctx, const float* pcm, int batch, float* mel_out) {
     if (!ctx) return MW_ERR_ARG;
-    int r = check_batch(ctx, batch, "mw_logmel");
+    int r = check_batch(ctx, batch, "mw_logmel", false);
     if (r) return r;
     if (!pcm) return fail(ctx, MW_ERR_ARG, "mw_logmel: pcm is null");
     HIPCHK(hipSetDevice(ctx->device));
@@ -743,7 +749,7 @@ extern "C" int mw_logmel(mw_ctx* ctx, const float* pcm, int batch, float* mel_ou
 // per-block maxima between the two launches live in this GPU's `scratch` array.
 extern "C" int mw_logmel_noalloc(mw_ctx* ctx, const float* pcm, int batch, float* mel_out) {
     if (!ctx) return MW_ERR_ARG;
-    int r = check_batch(ctx, batch, "mw_logmel_noalloc");
+    int r = check_batch(ctx, batch, "mw_logmel_noalloc", false);
     if (r) return r;
     if (batch > kNoAllocMaxBatch)
         return fail(ctx, MW_ERR_ARG, "mw_logmel_noalloc: batch exceeds the static scratch (" + std::to_string(kNoAllocMaxBatch) + " chunks)");
@@ -847,8 +853,8 @@ static int run_cross_kv(mw_ctx* ctx, int B, mw_ctx* dst = nullptr, int slot0 = 0
     if (!dst) dst = ctx;
     const mw_model_desc& d = ctx->d;
     const int D = d.d_model, H = d.n_heads, T = d.n_audio_ctx, M = B * T;
-    const size_t per_layer = (size_t)dst->max_batch * T * D;
-    const size_t at_slot = (size_t)slot0 * T * D;              // [L][max_batch][H][T][64]: a sequence is H*T*64 = T*D elements
+    const size_t per_layer = (size_t)dst->cache_seqs * T * D;
+    const size_t at_slot = (size_t)slot0 * T * D;              // [L][cache_seqs][H][T][64]: a sequence is H*T*64 = T*D elements
     for (int li = 0; li < d.dec_layers; ++li) {
         GemmParams p = gemm_base(ctx->enc_out, D, ctx->ckv_w + (size_t)li * 2 * D * D, D, M, 2 * D, D, ctx->ckv_b + (size_t)li * 2 * D);
         if (ctx->fp8) {           // encoder output rows as the final LayerNorm quantised them (xn8, xs)
@@ -857,7 +863,7 @@ static int run_cross_kv(mw_ctx* ctx, int B, mw_ctx* dst = nullptr, int slot0 = 0
         }
         p.out_mode = OUT_KV_SPLIT;
         if (ctx->kv8) {
-            const size_t per_layer_rows = (size_t)dst->max_batch * T * H, rows_at_slot = (size_t)slot0 * T * H;
+            const size_t per_layer_rows = (size_t)dst->cache_seqs * T * H, rows_at_slot = (size_t)slot0 * T * H;
             p.out_mode = OUT_KV_SPLIT8; p.k8 = dst->crossK8 + li * per_layer + at_slot; p.v8 = dst->crossV8 + li * per_layer + at_slot;
             p.ks = dst->crossKs + li * per_layer_rows + rows_at_slot; p.vs = dst->crossVs + li * per_layer_rows + rows_at_slot;
         } else {
@@ -906,7 +912,7 @@ extern "C" int mw_encode(mw_ctx* ctx, const float* mel, int batch, float* enc_ou
 static void cross_attention(mw_ctx* ctx, int li, const f16* q, f16* out, int rows, int kv_div = 1, int row0 = 0,
                             const int* done = nullptr, int done_div = 1) {
     const mw_model_desc& d = ctx->d;
-    const size_t per_layer = (size_t)ctx->max_batch * d.n_audio_ctx * d.d_model;
+    const size_t per_layer = (size_t)ctx->cache_seqs * d.n_audio_ctx * d.d_model;
     // Several hypotheses per recording (beam search, best-of-n samples): the rows of a recording share its K/V, so one
     // workgroup per (recording, head) reads them ONCE for all of them (the prompt prefill's kernel; the single-query
     // kernel reads them once per hypothesis).  MW_SHARED_XATTN=0: the single-query kernel.
@@ -914,7 +920,7 @@ static void cross_attention(mw_ctx* ctx, int li, const f16* q, f16* out, int row
     if (!shared_off && kv_div > 1 && row0 == 0 && rows % kv_div == 0) {
         const int n_rec = rows / kv_div;
         if (ctx->kv8) {
-            const size_t per_layer_rows = (size_t)ctx->max_batch * d.n_audio_ctx * d.n_heads;
+            const size_t per_layer_rows = (size_t)ctx->cache_seqs * d.n_audio_ctx * d.n_heads;
             launch_prefill_cross_attn8(q, ctx->crossK8 + li * per_layer, ctx->crossV8 + li * per_layer, ctx->crossKs + li * per_layer_rows,
                                        ctx->crossVs + li * per_layer_rows, out, n_rec, kv_div, d.n_heads, d.n_audio_ctx, 1, ctx->stream, done,
                                        done_div);
@@ -925,7 +931,7 @@ static void cross_attention(mw_ctx* ctx, int li, const f16* q, f16* out, int row
         return;
     }
     if (ctx->kv8) {
-        const size_t per_layer_rows = (size_t)ctx->max_batch * d.n_audio_ctx * d.n_heads;
+        const size_t per_layer_rows = (size_t)ctx->cache_seqs * d.n_audio_ctx * d.n_heads;
         launch_dec_cross_attn8(q, ctx->crossK8 + li * per_layer, ctx->crossV8 + li * per_layer, ctx->crossKs + li * per_layer_rows,
                                ctx->crossVs + li * per_layer_rows, out, rows, d.n_heads, d.n_audio_ctx, ctx->xpartial, ctx->xtickets,
                                ctx->stream, kv_div, row0, done, done_div, ctx->xattn_stream_from, ctx->xattn_stream_per_cu);
@@ -1062,9 +1068,9 @@ static int run_prefill(mw_ctx* ctx, int B, int P, int beam = 1, int* src_rows = 
         launch_layernorm(ctx->x, l.ln2.g, l.ln2.b, ctx->xn, nullptr, M, D, s);
         {   GemmParams p = gemm(ctx->xn, D, l.cq, D); p.scale = qscale; p.scale_ncols = D; p.C = cq; p.ldc = D; launch_gemm(p, s); }
         {   // every prompt row of a sequence against the cached encoder K/V of its recording, one pass of the keys
-            const size_t per_layer = (size_t)ctx->max_batch * d.n_audio_ctx * D;
+            const size_t per_layer = (size_t)ctx->cache_seqs * d.n_audio_ctx * D;
             if (ctx->kv8) {
-                const size_t per_layer_rows = (size_t)ctx->max_batch * d.n_audio_ctx * H;
+                const size_t per_layer_rows = (size_t)ctx->cache_seqs * d.n_audio_ctx * H;
                 launch_prefill_cross_attn8(cq, ctx->crossK8 + li * per_layer, ctx->crossV8 + li * per_layer, ctx->crossKs + li * per_layer_rows,
                                            ctx->crossVs + li * per_layer_rows, ctx->att, B, P, H, d.n_audio_ctx, kv_rep, s);
             } else {
@@ -1218,6 +1224,7 @@ extern "C" int mw_decode_beam(mw_ctx* ctx, int n_audio, int beam, float patience
     if (!(patience >= 1.0f) || patience > 4.0f) return fail(ctx, MW_ERR_ARG, "mw_decode_beam: patience must be in [1, 4]");
     if (n_audio < 1 || n_audio * beam > ctx->max_batch)
         return fail(ctx, MW_ERR_ARG, "mw_decode_beam: n_audio * beam must be in 1.." + std::to_string(ctx->max_batch) + " (max_batch)");
+    if (n_audio > ctx->cache_seqs) return fail(ctx, MW_ERR_ARG, "mw_decode_beam: n_audio exceeds the K/V cache (" + std::to_string(ctx->cache_seqs) + " recordings)");
     if (ctx->enc_batch != n_audio) return fail(ctx, MW_ERR_STATE, "mw_decode_beam: n_audio differs from the last mw_encode");
     if (!out_ids || !out_len) return fail(ctx, MW_ERR_ARG, "mw_decode_beam: null output");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1343,6 +1350,7 @@ extern "C" int mw_decode_sample(mw_ctx* ctx, int n_audio, int best_of, float tem
     if (!(temperature >= 0.0f) || temperature > 100.0f) return fail(ctx, MW_ERR_ARG, "mw_decode_sample: temperature must be in [0, 100]");
     if (n_audio < 1 || n_audio * best_of > ctx->max_batch)
         return fail(ctx, MW_ERR_ARG, "mw_decode_sample: n_audio * best_of must be in 1.." + std::to_string(ctx->max_batch) + " (max_batch)");
+    if (n_audio > ctx->cache_seqs) return fail(ctx, MW_ERR_ARG, "mw_decode_sample: n_audio exceeds the K/V cache (" + std::to_string(ctx->cache_seqs) + " recordings)");
     if (ctx->enc_batch != n_audio) return fail(ctx, MW_ERR_STATE, "mw_decode_sample: n_audio differs from the last mw_encode");
     if (!out_ids || !out_len) return fail(ctx, MW_ERR_ARG, "mw_decode_sample: null output");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1483,8 +1491,8 @@ extern "C" int mw_encode_into(mw_ctx* ctx, const float* pcm, int batch, mw_ctx* 
     const mw_ctx* root_a = ctx->parent ? ctx->parent : ctx;
     const mw_ctx* root_b = dst->parent ? dst->parent : dst;
     if (root_a != root_b) return fail(ctx, MW_ERR_ARG, "mw_encode_into: both contexts must share weights (an engine and its forks)");
-    if (slot0 < 0 || slot0 + batch > dst->max_batch)
-        return fail(ctx, MW_ERR_ARG, "mw_encode_into: slot0 + batch must fit the destination's max_batch (" + std::to_string(dst->max_batch) + ")");
+    if (slot0 < 0 || slot0 + batch > dst->cache_seqs)
+        return fail(ctx, MW_ERR_ARG, "mw_encode_into: slot0 + batch must fit the destination's cache (" + std::to_string(dst->cache_seqs) + " sequences)");
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const float* src = pcm;
@@ -1524,7 +1532,7 @@ extern "C" int mw_read_cross_kv(mw_ctx* ctx, int layer, int sequence, float* k_o
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const size_t per_seq = (size_t)d.n_heads * d.n_audio_ctx * kHeadDim;                 // elements of one sequence in one layer
-    const size_t at = ((size_t)layer * ctx->max_batch + sequence) * per_seq;
+    const size_t at = ((size_t)layer * ctx->cache_seqs + sequence) * per_seq;
     if (ctx->kv8) {
         const size_t rows = per_seq / kHeadDim;
         std::vector<uint8_t> codes(per_seq);
@@ -1627,7 +1635,7 @@ extern "C" int mw_profile_cross_attention(mw_ctx* ctx, int batch, int iters, flo
 // on the context's stream, launch boundaries included) and the weight bytes a layer's six matrices hold.
 extern "C" int mw_profile_decode_gemvs(mw_ctx* ctx, int batch, int iters, float* mean_ms_per_layer, double* weight_bytes_per_layer) {
     if (!ctx) return MW_ERR_ARG;
-    int r = check_batch(ctx, batch, "mw_profile_decode_gemvs");
+    int r = check_batch(ctx, batch, "mw_profile_decode_gemvs", false);
     if (r) return r;
     if (iters < 1 || !mean_ms_per_layer || !weight_bytes_per_layer) return fail(ctx, MW_ERR_ARG, "mw_profile_decode_gemvs: bad argument");
     if (!ctx->opts_set) return fail(ctx, MW_ERR_STATE, "mw_profile_decode_gemvs: call mw_set_decode_opts first");

@@ -51,6 +51,7 @@ class Engine:
         self.dims = dims
         self.device = device
         self.max_batch = max_batch
+        self.cache_sequences = max_batch
         self.opts: Optional[DecodeOptions] = None
         if weight_format not in _lib.WEIGHT_FORMATS:
             raise EngineError(f"weight_format={weight_format!r}: expected one of {sorted(_lib.WEIGHT_FORMATS)}")
@@ -67,14 +68,19 @@ class Engine:
         self._h = h
         self._forks = []
 
-    def fork(self, max_batch: Optional[int] = None) -> "Engine":
+    def fork(self, max_batch: Optional[int] = None, cache_sequences: Optional[int] = None) -> "Engine":
         """A second engine on the same GPU sharing these weights (own stream and caches, sized for
-        ``max_batch`` chunks: this engine's by default); safe to drive from another thread while this one is busy."""
+        ``max_batch`` chunks: this engine's by default); safe to drive from another thread while this one is busy.
+        ``cache_sequences``: chunks its cross-attention K/V cache holds (default ``max_batch``); an engine that decodes
+        several hypotheses per chunk (beam search, best-of-n) needs ``max_batch`` = chunks x hypotheses sequences but
+        a cache for the chunks only (``mw_fork_cached``)."""
         h = C.c_void_p()
         max_batch = self.max_batch if max_batch is None else int(max_batch)
-        self._check(self._lib.mw_fork_sized(self._h, max_batch, C.byref(h)), "mw_fork_sized")
+        cache = max_batch if cache_sequences is None else int(cache_sequences)
+        self._check(self._lib.mw_fork_cached(self._h, max_batch, cache, C.byref(h)), "mw_fork_cached")
         child = object.__new__(Engine)
         child._lib, child.dims, child.device, child.max_batch = self._lib, self.dims, self.device, max_batch
+        child.cache_sequences = cache
         child.weight_format, child.kv_format = self.weight_format, self.kv_format
         child.opts = self.opts
         child._h = h

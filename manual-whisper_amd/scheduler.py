@@ -46,7 +46,11 @@ class EnginePool:
     the chip idle; a second and third engine (own stream and caches, shared weights) fill those gaps.
     """
 
-    def __init__(self, engine, n_engines: int = 1, beam_size: int = 1, patience: float = 1.0, fallback=None, detokenize=None):
+    def __init__(self, engine, n_engines: int = 1, beam_size: int = 1, patience: float = 1.0, fallback=None, detokenize=None,
+                 fork_batch: Optional[int] = None, fork_cache: Optional[int] = None):
+        """``fork_batch`` (with ``fork_cache``): every engine of the pool is a fork of `engine` sized for that many
+        sequences with a cross-attention K/V cache for ``fork_cache`` chunks (several hypotheses per chunk share the
+        chunk's cache), and `engine` itself only lends its weights."""
         if n_engines < 1:
             raise ValueError("n_engines must be >= 1")
         self.beam_size, self.patience = int(beam_size), float(patience)
@@ -57,7 +61,11 @@ class EnginePool:
         if self.fallback is not None and detokenize is None:
             raise ValueError("temperature fallback needs detokenize")
         _lib.check_hw_queues(n_engines)              # one stream per engine
-        self.engines = [engine] + [engine.fork() for _ in range(n_engines - 1)]
+        self.root = engine
+        if fork_batch is not None:
+            self.engines = [engine.fork(int(fork_batch), int(fork_cache or fork_batch)) for _ in range(n_engines)]
+        else:
+            self.engines = [engine] + [engine.fork() for _ in range(n_engines - 1)]
         if n_engines > 1:       # engines that share the GPU: see GroupedPool
             for e in self.engines:
                 e.set_option("xattn_stream_per_cu", int(os.environ.get("MW_XSTREAM_PER_CU", "1")))
@@ -91,6 +99,7 @@ class EnginePool:
         self._pool.shutdown(wait=True)
         for e in reversed(self.engines):
             e.close()
+        self.root.close()
 
 
 def group_sizes(n_batches: int, group: int) -> List[int]:

@@ -213,3 +213,42 @@ def test_beam_search_with_a_long_prompt_prefilled(name, n_prompt):
         assert eng.stage_ms()["decode_steps"] == n_prompt + 8 - 1          # positions processed, prefilled ones included
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_fork_with_a_cache_for_the_recordings_only():
+    """mw_fork_cached: an engine for n recordings x b hypotheses holds n cached recordings.  Beam search and best-of-n on
+    it give what an engine with a slot per sequence gives; what needs a slot per sequence is refused beyond n."""
+    from manual_whisper_amd.engine import Engine, EngineError
+    dims = mw.get_dims("micro")
+    w = synth.make_weights_np(dims, 1234)
+    pcm = synth.make_pcm_np(4, seed=5)
+    full = Engine(dims, 0, 20)
+    try:
+        full.load_weights(w)
+        o = synthetic_options(dims, max_new=10)
+        full.set_decode_options(o)
+        lean = full.fork(20, cache_sequences=4)
+        assert lean.max_batch == 20 and lean.cache_sequences == 4
+        lean.set_decode_options(o)
+        got = []
+        for e in (full, lean):
+            e.logmel(pcm, want_output=False)
+            e.encode(4, want_output=False)
+            got.append(e.decode_beam(4, 5, 1.0, want_hypotheses=True))
+        for a, b in zip(got[0], got[1]):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+        ids_g, lens_g = lean.decode_greedy(4)[:2]
+        want_g, want_l = full.decode_greedy(4)[:2]
+        assert (ids_g == want_g).all() and (lens_g == want_l).all()
+        five = synth.make_pcm_np(5, seed=6)
+        lean.logmel(five, want_output=False)                      # log-mel has no cache to fill: 5 <= max_batch is fine
+        with pytest.raises(EngineError):
+            lean.encode(5, want_output=False)
+        with pytest.raises(EngineError):
+            lean.decode_beam(5, 4)
+        with pytest.raises(EngineError):
+            full.fork(8, cache_sequences=9)
+        lean.close()
+    finally:
+        full.close()

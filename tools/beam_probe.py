@@ -21,10 +21,13 @@ engines = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 passes = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 dev = torch.device("cuda", 0)
 dims = mw.get_dims("large-v3")
-eng = Engine(dims, device=0, max_batch=n_rec * beam, weight_format=os.environ.get("MW_WEIGHTS", "f16"), kv_format=os.environ.get("MW_KV", "f16"))
+cached = os.environ.get("MW_BEAM_CACHED", "1") == "1"      # forks whose K/V cache holds the recordings once (what load_model builds)
+eng = Engine(dims, device=0, max_batch=16 if cached else n_rec * beam, weight_format=os.environ.get("MW_WEIGHTS", "f16"),
+             kv_format=os.environ.get("MW_KV", "f16"))
 eng.load_weights(synth.make_weights_torch(dims, seed=1234, device=dev))
 eng.set_decode_options(synthetic_options(dims, max_new=128, suppress_eot=True))
-pool = EnginePool(eng, engines, beam_size=beam)
+pool = EnginePool(eng, engines, beam_size=beam, fork_batch=n_rec * beam, fork_cache=n_rec) if cached else EnginePool(eng, engines, beam_size=beam)
+pool.set_decode_options(synthetic_options(dims, max_new=128, suppress_eot=True))
 pcms = [synth.make_pcm_torch(n_rec, seed=i, device=dev) for i in range(3)]
 pool.map([pcms[i % 3] for i in range(engines)])           # graphs captured
 torch.cuda.synchronize()
