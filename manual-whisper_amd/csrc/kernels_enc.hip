@@ -144,13 +144,11 @@ __global__ void bcast_rows_kernel(const float* __restrict__ table, float* __rest
 // position there), so the scores are exponents of 2, and the score accumulators start at minus the query's
 // reference exponent: per score the softmax costs one v_exp_f32, one add, a third of a max3 and half a convert, no
 // multiply or subtract.  The
-// reference is the first tile's maximum and is only raised when some query of the wave exceeds it by more than
-// kRescaleGap, so the O / l rescale is skipped for almost every tile; P then reaches at most 2^kRescaleGap, far
-// inside fp16 range.  (This file is compiled with -fno-honor-nans: the maxima of MFMA results then need no
-// canonicalising v_max x, x each.)
+// reference is the first tile's maximum and is only raised when some score of the wave outgrows it (see the kernel),
+// so the O / l rescale is skipped for almost every tile.  (This file is compiled with -fno-honor-nans: the maxima of
+// MFMA results then need no canonicalising v_max x, x each.)
 constexpr int AQ = 128, AKV = 64;
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kRescaleGap = 6.0f;
 
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
@@ -172,11 +170,25 @@ __device__ __forceinline__ float quad_column_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-// Three workgroups per CU (158 VGPRs instead of the 200 the compiler takes when left alone, no spills): with a
-// third wave per SIMD the MFMA, exp and LDS phases of different waves overlap; 401 -> 316 us at batch 16.
+// Three workgroups per CU (no spills under the 168 registers that leaves): with a third wave per SIMD the MFMA, exp
+// and LDS phases of different waves overlap; 401 -> 316 us at batch 16.  Counters then show the vector issue port as
+// the busiest unit (about 960 of its cycles per wave and key tile, 256 of them the exponentials, against 512 of the
+// matrix pipe), so the loop is written to issue as few vector instructions as it can:
+//  * K and V^T tiles come through buffer loads: the range check of the descriptor zero-fills keys past the end, the
+//    only a tile offset is added per load, and no lane computes a 64-bit address or a predicate inside the loop.  A V^T
+//    chunk that straddles the end of a row reads on into the next row; those keys carry weight 0 exactly (masked
+//    scores), and the bytes are V values of the same tensor, so finite.
+//  * no per-tile maximum.  The scores come out of the MFMAs relative to the running reference exponent; whether that
+//    reference still holds is read off the lane's own sum of the 16 weights it just formed (needed anyway): a sum
+//    above kSumLimit means some score outgrew the reference, and only then (and for the first tile, which sets the
+//    reference) is the tile's maximum taken, the reference raised, O and l rescaled and the tile's scores formed
+//    again from the K tile still in LDS.  Weights stay below kSumLimit, far inside fp16 range.
 // VARLEN (a packed batch of recordings of different lengths, the forced aligner's): batch element b has keys_of[b] <= T
 // keys (and as many queries that matter); its rows still lie T apart.  T below is then the element's own length
 // wherever keys are counted; workgroups whose queries all lie past it have nothing to do.
+constexpr float kSumLimit = 1024.0f;
+typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
+
 template <bool VARLEN>
 __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                             const f16* __restrict__ vT, f16* __restrict__ out, int H,
@@ -199,8 +211,6 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
         if ((bid - bh * nqt) * AQ >= T) return;                 // (workgroup-uniform, before any barrier)
     }
     const f16* qb = q + (long)bh * Tstride * 64;
-    const f16* kb = k + (long)bh * Tstride * 64;
-    const f16* vb = vT + (long)bh * 64 * Tpad;
 
     // Q fragments (B operand: column = query, k = head-dim), straight from global.
     half8 qf[2][2];
@@ -216,52 +226,51 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
         }
     }
 
-    // staging: each thread moves two 16-byte chunks of K and two of V^T per tile
-    uint4 rk[2], rv[2];
+    // staging: each thread moves two 16-byte chunks of K and two of V^T per tile.  K rows of this (batch, head) are
+    // one buffer of T rows; V^T is one buffer of 64 rows of Tpad keys.
+    const __amdgpu_buffer_rsrc_t krs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(k + (long)bh * Tstride * 64), 0, T * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(vT + (long)bh * 64 * Tpad), 0, 64 * Tpad * 2, 0x00020000);
+    u32x4e rk[2], rv[2];
     const int ch = tid & 7;
+    const int kvoff = (tid >> 3) * 128 + ch * 16;                  // byte offsets inside a tile, per thread
+    const int vvoff = (tid >> 3) * Tpad * 2 + ch * 16;
+    const int vrow32 = 32 * Tpad * 2;
     auto gload = [&](int kv0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (tid >> 3) + 32 * i;
-            const int key = kv0 + row;
-            rk[i] = key < T ? *reinterpret_cast<const uint4*>(kb + (long)key * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
-            const int kc = kv0 + ch * 8;             // V^T: row = head-dim index, chunk = 8 keys
-            rv[i] = kc < Tpad ? *reinterpret_cast<const uint4*>(vb + (long)row * Tpad + kc) : make_uint4(0, 0, 0, 0);
-        }
+        // (the whole offset in the vector operand: that is the one the descriptor's range check covers)
+        rk[0] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff + kv0 * 128, 0, 0);
+        rk[1] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff + (kv0 * 128 + 32 * 128), 0, 0);
+        rv[0] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff + kv0 * 2, 0, 0);
+        rv[1] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff + (kv0 * 2 + vrow32), 0, 0);
     };
     // V^T key permutation inside a tile: key 32s + 16h + 4g + r  ->  column 32s + 8g + 4h + r, i.e. the
     // source chunk c (keys 8c..8c+7: s = c>>2, h = (c>>1)&1, g = 2(c&1), 2(c&1)+1) lands as two
     // 8-byte pieces in destination chunks 4s + 2(c&1) and 4s + 2(c&1) + 1, at half-offset 4h.
     const int vdst_chunk = (ch & 4) + 2 * (ch & 1), vdst_off = 4 * ((ch >> 1) & 1);
+    const int row_a = tid >> 3;
+    const int kdst = swz64(row_a, ch), kdst2 = swz64(row_a + 32, ch);
+    const int vdst_a = swz64(row_a, vdst_chunk) + vdst_off, vdst_b = swz64(row_a, vdst_chunk + 1) + vdst_off;
+    const int vdst_c = swz64(row_a + 32, vdst_chunk) + vdst_off, vdst_d = swz64(row_a + 32, vdst_chunk + 1) + vdst_off;
     auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (tid >> 3) + 32 * i;
-            *reinterpret_cast<uint4*>(&lds[buf][0][swz64(row, ch)]) = rk[i];
-            *reinterpret_cast<uint2*>(&lds[buf][1][swz64(row, vdst_chunk) + vdst_off]) = make_uint2(rv[i].x, rv[i].y);
-            *reinterpret_cast<uint2*>(&lds[buf][1][swz64(row, vdst_chunk + 1) + vdst_off]) = make_uint2(rv[i].z, rv[i].w);
-        }
+        *reinterpret_cast<u32x4e*>(&lds[buf][0][kdst]) = rk[0];
+        *reinterpret_cast<u32x4e*>(&lds[buf][0][kdst2]) = rk[1];
+        *reinterpret_cast<uint2*>(&lds[buf][1][vdst_a]) = make_uint2(rv[0][0], rv[0][1]);
+        *reinterpret_cast<uint2*>(&lds[buf][1][vdst_b]) = make_uint2(rv[0][2], rv[0][3]);
+        *reinterpret_cast<uint2*>(&lds[buf][1][vdst_c]) = make_uint2(rv[1][0], rv[1][1]);
+        *reinterpret_cast<uint2*>(&lds[buf][1][vdst_d]) = make_uint2(rv[1][2], rv[1][3]);
     };
 
     float4v o[4][2];           // [head-dim tile][query tile]: O^T
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[i][0] = float4v{0, 0, 0, 0}; o[i][1] = float4v{0, 0, 0, 0}; }
-    // Reference exponent per query (log2 units).  The score
-    // accumulators START at -mrun, so the MFMAs deliver score - mrun and the exponentials take them as they come.
-    // It is set from the first tile's maxima and raised only when a later tile exceeds it by more than kRescaleGap.
+    // Reference exponent per query (log2 units).  The score accumulators START at -mrun, so the MFMAs deliver
+    // score - mrun and the exponentials take them as they come.
     float mrun[2] = {0.f, 0.f};
     float lrun[2] = {0.f, 0.f};
+    float4v sc[4][2];          // S^T tiles: [key tile i][query tile qs], relative to the reference exponent
 
-    const int ntile = (T + AKV - 1) / AKV;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int it = 0; it < ntile; ++it) {
-        const int buf = it & 1, kv0 = it * AKV;
-        if (it + 1 < ntile) gload(kv0 + AKV);
-
-        // ---- S^T tiles: [key tile i][query tile qs], relative to the reference exponent
-        float4v sc[4][2];
+    auto scores = [&](int buf, int kv0) {
         const float n0 = -mrun[0], n1 = -mrun[1];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -280,49 +289,69 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
                 for (int r = 0; r < 4; ++r)
                     if (kv0 + i * 16 + 4 * fg + r >= T) { sc[i][0][r] = -1.0e30f; sc[i][1][r] = -1.0e30f; }
         }
-        // ---- online softmax per query column
-        float mx[2];
+    };
+    // the tile's maxima become part of the reference (first tile: they ARE the reference, nothing to rescale yet)
+    auto raise_reference = [&](bool first) {
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
             float m = fmaxf(fmaxf(sc[0][qs][0], sc[0][qs][1]), fmaxf(sc[0][qs][2], sc[0][qs][3]));
 #pragma unroll
             for (int i = 1; i < 4; ++i) m = fmaxf(m, fmaxf(fmaxf(sc[i][qs][0], sc[i][qs][1]), fmaxf(sc[i][qs][2], sc[i][qs][3])));
-            mx[qs] = quad_column_max(m);
-        }
-        if (it == 0 || __any(mx[0] > kRescaleGap || mx[1] > kRescaleGap)) {     // wave-uniform, rare after the first tile
+            const float mx = quad_column_max(m);
+            const float delta = first ? mx : fmaxf(mx, 0.f);
+            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+            mrun[qs] += delta;
+            lrun[qs] *= alpha;
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs) {
-                // first tile: the reference becomes its maximum (nothing accumulated yet, so nothing to rescale)
-                const float delta = it == 0 ? mx[qs] : fmaxf(mx[qs], 0.f);
-                const float alpha = it == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
-                mrun[qs] += delta;
-                lrun[qs] *= alpha;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    o[i][qs][0] *= alpha; o[i][qs][1] *= alpha; o[i][qs][2] *= alpha; o[i][qs][3] *= alpha;
-                    sc[i][qs][0] -= delta; sc[i][qs][1] -= delta; sc[i][qs][2] -= delta; sc[i][qs][3] -= delta;
-                }
+            for (int i = 0; i < 4; ++i) {
+                o[i][qs][0] *= alpha; o[i][qs][1] *= alpha; o[i][qs][2] *= alpha; o[i][qs][3] *= alpha;
+                sc[i][qs][0] -= delta; sc[i][qs][1] -= delta; sc[i][qs][2] -= delta; sc[i][qs][3] -= delta;
             }
         }
-        half8 pf[2][2];            // [query tile][k step of 32 keys]
+    };
+    float ps[2];
+    auto weights = [&]() {      // scores -> weights in place; ps = this lane's sums
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
-            float ps = 0.f;
+            float a = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pv = __builtin_amdgcn_exp2f(sc[i][qs][r]);
                     sc[i][qs][r] = pv;
-                    ps += pv;
+                    a += pv;
                 }
-            lrun[qs] += ps;                              // partial over this lane's keys; reduced at the end
+            ps[qs] = a;
+        }
+    };
+
+    const int ntile = (T + AKV - 1) / AKV;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const int buf = it & 1, kv0 = it * AKV;
+        if (it + 1 < ntile) gload(kv0 + AKV);
+
+        scores(buf, kv0);
+        if (it == 0) raise_reference(true);
+        weights();
+        if (__any(ps[0] > kSumLimit || ps[1] > kSumLimit)) {     // wave-uniform, rare: some score outgrew the reference
+            scores(buf, kv0);
+            raise_reference(false);
+            weights();
+        }
+        lrun[0] += ps[0];                                // partial over this lane's keys; reduced at the end
+        lrun[1] += ps[1];
+        half8 pf[2][2];            // [query tile][k step of 32 keys]
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 pf[qs][s] = half8{(f16)sc[2 * s][qs][0], (f16)sc[2 * s][qs][1], (f16)sc[2 * s][qs][2], (f16)sc[2 * s][qs][3],
                                   (f16)sc[2 * s + 1][qs][0], (f16)sc[2 * s + 1][qs][1], (f16)sc[2 * s + 1][qs][2],
                                   (f16)sc[2 * s + 1][qs][3]};
-        }
         // ---- O^T += V^T P^T ; element j of k-step s is key 32s + 16(j>>2) + 4*fg + (j&3) = permuted column 32s + 8fg + j
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {

@@ -292,8 +292,19 @@ def test_ended_sequences_are_skipped_without_changing_ids(B, formats):
             eng.set_option("skip_done", 0)
             ids3, lens3 = eng.transcribe_batch(pcm)
             eng.set_option("skip_done", 1)
+            assert (ids3 == ids2).all() and (lens3 == lens2).all()
+            # against the other form (another summation order over the keys): the two allowed ids were picked to be
+            # close rivals, so a row may part where this form's own logits hold them within a tie's width
+            eng.logmel(pcm, want_output=False)
+            eng.encode(B, want_output=False)
+            _, _, path = eng.decode_greedy(B, want_logits=True)
             eng.set_option("xattn_stream_from", 1024)
-            assert (ids2 == ids1).all() and (lens2 == lens1).all() and (ids3 == ids1).all() and (lens3 == lens1).all()
+            apart = np.nonzero((ids2 != ids1).any(axis=1))[0]
+            assert len(apart) <= max(2, B // 8), apart
+            for r in apart:
+                pos = int(np.nonzero(ids2[r] != ids1[r])[0][0])
+                gap = float(path[pos, r, ids2[r, pos]] - path[pos, r, ids1[r, pos]])
+                assert abs(gap) < TIE_GAP, (int(r), pos, gap)
         if formats[0] == "f16":
             orc = WhisperOracle(dims, w)
             sel = np.arange(0, B, 5)

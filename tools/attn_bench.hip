@@ -87,7 +87,7 @@ int main(int argc, char** argv) {
     printf("check: %d rows, max |err| %.5f, mismatches %ld\n", nr, maxerr, bad);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 2; ++i) launch_enc_attention(q, k, vT, out, B, H, T, Tpad, s);
-    const int iters = 10;
+    const int iters = 50;
     CK(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i) launch_enc_attention(q, k, vT, out, B, H, T, Tpad, s);
     CK(hipEventRecord(e1, s));

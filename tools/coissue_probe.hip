@@ -7,13 +7,25 @@
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
 
-// mode bit 0: waves 0-3 do MFMAs; bit 1: waves 4-7 do exponentials; bit 2: waves 4-7 do FMAs instead
+// mode bit 0: waves 0-3 do MFMAs; bit 1: waves 4-7 do exponentials; bit 2: waves 4-7 do FMAs instead;
+// bit 3: the MFMAs are v_mfma_f32_32x32x16_f16 (half as many, twice the work each)
 __global__ __launch_bounds__(512) void probe(float* out, int iters, int mode) {
     const int wave = threadIdx.x >> 6;
     float r = 0.f;
     if (wave < 4) {
-        if (mode & 1) {
+        if ((mode & 9) == 9) {
+            half8 a, b;
+            for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(threadIdx.x * 0.001f + e); b[e] = (_Float16)(e * 0.5f); }
+            float16v c[4];
+            for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) c[i][e] = 0.f;
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c[i], 0, 0, 0);
+            }
+            for (int i = 0; i < 4; ++i) r += c[i][0] + c[i][5] + c[i][10] + c[i][15];
+        } else if (mode & 1) {
             half8 a, b;
             for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(threadIdx.x * 0.001f + e); b[e] = (_Float16)(e * 0.5f); }
             float4v c[8];
@@ -64,6 +76,12 @@ int main() {
                m * 1950.0 / (iters * 8.0), e, e * 1950.0 / (iters * 8.0), f);
         printf("  MFMA wave + exp wave on every SIMD: %.0f us (max %.0f, sum %.0f);  MFMA wave + FMA wave: %.0f us (max %.0f, sum %.0f)\n", me,
                m > e ? m : e, m + e, mf, m > f ? m : f, m + f);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        const float m = run(out, iters, 9), e = run(out, iters, 2), f = run(out, iters, 4);
+        const float me = run(out, iters, 11), mf = run(out, iters, 13);
+        printf("32x32x16: MFMA alone %.0f us (%.1f cycles per MFMA at 1.95 GHz); + exp wave %.0f us (max %.0f, sum %.0f); + FMA wave %.0f us (max %.0f, sum %.0f)\n",
+               m, m * 1950.0 / (iters * 4.0), me, m > e ? m : e, m + e, mf, m > f ? m : f, m + f);
     }
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return 0;
