@@ -1785,8 +1785,14 @@ __device__ __forceinline__ float pf_column_sum(float v) {
 // key tiles past a workgroup's last row are never staged, and every workgroup files the k / v rows of its own 128 prompt
 // positions in the layer's cache (kcache / vcache [cache sequences][H][Tctx][64]; sequence b under cache sequence
 // b * cache_seq_stride), where the sampled positions will find them.
-template <bool KV8, bool CAUSAL = false>
-__global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* __restrict__ q, const void* __restrict__ kc,
+// QT = 1: at most 16 query rows per (sequence, head) (the hypotheses of a recording in beam search or best-of-n
+// sampling, one decode position each).  One wave per workgroup then has rows at all, with one 16-column tile; which
+// wave it is rotates with the workgroup id, so that the workgroups sharing a CU compute on different SIMDs.  Such a
+// launch is nothing but a stream of K/V through the CUs, and what it reaches depends on the bytes in flight: four
+// workgroups per CU (the registers of the second query tile are free) and TWO tiles on their way per workgroup
+// instead of one (one set of staging registers is filed in LDS while the other is still in flight).
+template <bool KV8, bool CAUSAL = false, int QT = 2>
+__global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void prefill_cross_attn_kernel(const f16* __restrict__ q, const void* __restrict__ kc,
                                                                     const void* __restrict__ vc, const float* __restrict__ ks,
                                                                     const float* __restrict__ vs, f16* __restrict__ out, int H,
                                                                     int P, int T, int kv_rep, f16* __restrict__ kcache = nullptr,
@@ -1794,6 +1800,8 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
                                                                     int cache_seq_stride = 1, const int* __restrict__ done = nullptr,
                                                                     int done_div = 1) {
     static_assert(!(KV8 && CAUSAL), "the self-attention cache is fp16");
+    static_assert(QT == 2 || !CAUSAL, "a prompt's self-attention has rows for every wave");
+    constexpr int DEPTH = QT == 1 ? 2 : 1;          // tiles in flight from global memory
     __shared__ __attribute__((aligned(16))) f16 ldsK[2][PFK * 64];
     __shared__ __attribute__((aligned(16))) f16 ldsV[2][PFK * PFVS];
     __shared__ __attribute__((aligned(16))) float ldsS[2][2][KV8 ? PFK : 4];
@@ -1809,15 +1817,15 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
         if (all_done) return;                   // (workgroup-uniform, before any barrier)
     }
     const long bh_kv = (long)(seq / kv_rep) * H + h;
-    const int q0 = qblock * PFQ + wave * 32;
-    const bool active = q0 < P;                 // wave-uniform
+    const int q0 = QT == 2 ? qblock * PFQ + wave * 32 : 0;
+    const bool active = QT == 2 ? q0 < P : wave == (int)(blockIdx.x & 3);          // wave-uniform
     const int D = H * 64;
     const long ldq = CAUSAL ? 3L * D : D;
     const f16* qbase = q + (long)seq * P * ldq + h * 64;
 
-    half8 qf[2][2];
+    half8 qf[QT][2];
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < QT; ++qs) {
         const int row = min(q0 + qs * 16 + fr, P - 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) qf[qs][s] = *reinterpret_cast<const half8*>(qbase + (long)row * ldq + s * 32 + fg * 8);
@@ -1837,10 +1845,10 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
 
     // staging: a thread moves two 8-element chunks of K and two of V per tile (16 bytes each, 8 in the e4m3 cache)
     typedef typename std::conditional<KV8, uint2, uint4>::type Chunk;
-    Chunk rk[2], rv[2];
-    float rscale = 0.f;
+    Chunk rk[DEPTH][2], rv[DEPTH][2];
+    float rscale[DEPTH] = {};
     const int ch = tid & 7;
-    auto gload = [&](int kv0) {
+    auto gload = [&](int kv0, Chunk (&rk)[2], Chunk (&rv)[2], float& rscale) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int key = kv0 + (tid >> 3) + 32 * i;
@@ -1874,7 +1882,7 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
             return c;
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const Chunk (&rk)[2], const Chunk (&rv)[2], float rscale) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (tid >> 3) + 32 * i;
@@ -1886,32 +1894,38 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
         }
     };
 
-    float4v o[4][2];           // [head-dim tile][query tile]: O^T
+    float4v o[4][QT];          // [head-dim tile][query tile]: O^T
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { o[i][0] = float4v{0, 0, 0, 0}; o[i][1] = float4v{0, 0, 0, 0}; }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int qs = 0; qs < QT; ++qs) o[i][qs] = float4v{0, 0, 0, 0};
     // reference exponent (log2 units) and sum per query; the reference rises only when a tile exceeds it by
     // more than kPfRescaleGap, so the accumulators are rarely rescaled after the first tile
-    float mrun[2] = {0.f, 0.f};
-    float lrun[2] = {0.f, 0.f};
+    float mrun[QT] = {};
+    float lrun[QT] = {};
 
     const int ntile = ((CAUSAL ? min(T, (qblock + 1) * PFQ) : T) + PFK - 1) / PFK;
-    gload(0);
-    lstore(0);
+    gload(0, rk[0], rv[0], rscale[0]);
+    lstore(0, rk[0], rv[0], rscale[0]);
+    if (DEPTH == 2 && ntile > 1) gload(PFK, rk[0], rv[0], rscale[0]);
     __syncthreads();
-    for (int it = 0; it < ntile; ++it) {
+    // one key tile: `cur` names the staging registers that hold (or are about to receive) tile it + 1
+    auto tile_step = [&](int it, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value, nxt = (cur + DEPTH - 1) % DEPTH;
         const int buf = it & 1, kv0 = it * PFK;
-        if (it + 1 < ntile) gload(kv0 + PFK);
+        if (it + DEPTH < ntile) gload(kv0 + DEPTH * PFK, rk[nxt], rv[nxt], rscale[nxt]);
         if (active && !(CAUSAL && kv0 > q0 + 31)) {          // (wave-uniform) causal: tiles past the wave's last row hold nothing for it
             // ---- S^T tiles: [key tile i][query tile qs]
-            float4v sc[4][2];
+            float4v sc[4][QT];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                sc[i][0] = float4v{0, 0, 0, 0}; sc[i][1] = float4v{0, 0, 0, 0};
+#pragma unroll
+                for (int qs = 0; qs < QT; ++qs) sc[i][qs] = float4v{0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const half8 kf = *reinterpret_cast<const half8*>(&ldsK[buf][pf_swz(i * 16 + fr, s * 4 + fg)]);
-                    sc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][s], sc[i][0], 0, 0, 0);
-                    sc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][s], sc[i][1], 0, 0, 0);
+#pragma unroll
+                    for (int qs = 0; qs < QT; ++qs) sc[i][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qs][s], sc[i][qs], 0, 0, 0);
                 }
             }
             // exponents of 2 relative to the reference; lane holds keys kv0 + 16i + 4fg + r of query fr
@@ -1923,23 +1937,27 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
                 for (int r = 0; r < 4; ++r) {
                     const int key = kv0 + i * 16 + 4 * fg + r;
                     const bool past = key >= T;
-                    const bool hid0 = CAUSAL && key > q0 + fr, hid1 = CAUSAL && key > q0 + 16 + fr;
-                    sc[i][0][r] = (past || hid0) ? -1.0e30f : fmaf(sc[i][0][r], kscale[r], -mrun[0]);
-                    sc[i][1][r] = (past || hid1) ? -1.0e30f : fmaf(sc[i][1][r], kscale[r], -mrun[1]);
+#pragma unroll
+                    for (int qs = 0; qs < QT; ++qs) {
+                        const bool hid = CAUSAL && key > q0 + 16 * qs + fr;
+                        sc[i][qs][r] = (past || hid) ? -1.0e30f : fmaf(sc[i][qs][r], kscale[r], -mrun[qs]);
+                    }
                 }
             }
             // ---- online softmax per query column
-            float mx[2];
+            float mx[QT];
+            bool lift = it == 0;
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs) {
+            for (int qs = 0; qs < QT; ++qs) {
                 float m = fmaxf(fmaxf(sc[0][qs][0], sc[0][qs][1]), fmaxf(sc[0][qs][2], sc[0][qs][3]));
 #pragma unroll
                 for (int i = 1; i < 4; ++i) m = fmaxf(m, fmaxf(fmaxf(sc[i][qs][0], sc[i][qs][1]), fmaxf(sc[i][qs][2], sc[i][qs][3])));
                 mx[qs] = pf_column_max(m);
+                lift = lift || mx[qs] > kPfRescaleGap;
             }
-            if (it == 0 || __any(mx[0] > kPfRescaleGap || mx[1] > kPfRescaleGap)) {     // wave-uniform
+            if (__any(lift)) {      // wave-uniform
 #pragma unroll
-                for (int qs = 0; qs < 2; ++qs) {
+                for (int qs = 0; qs < QT; ++qs) {
                     const float delta = it == 0 ? mx[qs] : fmaxf(mx[qs], 0.f);
                     const float alpha = it == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
                     mrun[qs] += delta;
@@ -1951,9 +1969,9 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
                     }
                 }
             }
-            half8 pf[2][2];            // [query tile][step of 32 keys]
+            half8 pf[QT][2];           // [query tile][step of 32 keys]
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs) {
+            for (int qs = 0; qs < QT; ++qs) {
                 float ps = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1985,19 +2003,23 @@ __global__ __launch_bounds__(256, 3) void prefill_cross_attn_kernel(const f16* _
                     const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(blk + 16 * PFVS));
                     const short8v both = short8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     const half8 vf = __builtin_bit_cast(half8, both);
-                    o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0][s], o[dt][0], 0, 0, 0);
-                    o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][s], o[dt][1], 0, 0, 0);
+#pragma unroll
+                    for (int qs = 0; qs < QT; ++qs) o[dt][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qs][s], o[dt][qs], 0, 0, 0);
                 }
             }
         }
-        if (it + 1 < ntile) lstore(buf ^ 1);
+        if (it + 1 < ntile) lstore(buf ^ 1, rk[cur], rv[cur], rscale[cur]);
         __syncthreads();
+    };
+    for (int it = 0; it < ntile; it += DEPTH) {
+        tile_step(it, std::integral_constant<int, 0>{});
+        if (DEPTH == 2 && it + 1 < ntile) tile_step(it + 1, std::integral_constant<int, DEPTH - 1>{});
     }
     if (!active) return;
 
     // ---- normalise and store: lane holds O[query fr][16dt + 4fg .. +3]
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < QT; ++qs) {
         const float inv = 1.0f / pf_column_sum(lrun[qs]);
         const int row = q0 + qs * 16 + fr;
         if (row < P) {
@@ -2379,15 +2401,25 @@ void launch_prefill_cross_attn(const f16* q, const f16* kc, const f16* vc, f16* 
                                hipStream_t s, const int* done, int done_div) {
     const float* none = nullptr;
     f16* nocache = nullptr;
-    hipLaunchKernelGGL(prefill_cross_attn_kernel<false>, dim3(B * H * ((P + PFQ - 1) / PFQ)), dim3(256), 0, s, q, kc, vc, none, none, out, H,
-                       P, T, kv_rep, nocache, nocache, 0, 1, done, done_div);
+    static const int narrow = getenv("MW_PREFILL_NARROW") ? atoi(getenv("MW_PREFILL_NARROW")) : 1;
+    if (P <= 16 && narrow)      // a decode position of a few hypotheses per recording: one query tile, deeper staging
+        hipLaunchKernelGGL((prefill_cross_attn_kernel<false, false, 1>), dim3(B * H), dim3(256), 0, s, q, kc, vc, none, none, out, H, P, T,
+                           kv_rep, nocache, nocache, 0, 1, done, done_div);
+    else
+        hipLaunchKernelGGL(prefill_cross_attn_kernel<false>, dim3(B * H * ((P + PFQ - 1) / PFQ)), dim3(256), 0, s, q, kc, vc, none, none,
+                           out, H, P, T, kv_rep, nocache, nocache, 0, 1, done, done_div);
 }
 
 void launch_prefill_cross_attn8(const f16* q, const uint8_t* k8, const uint8_t* v8, const float* ks, const float* vs, f16* out, int B,
                                 int P, int H, int T, int kv_rep, hipStream_t s, const int* done, int done_div) {
     f16* nocache = nullptr;
-    hipLaunchKernelGGL(prefill_cross_attn_kernel<true>, dim3(B * H * ((P + PFQ - 1) / PFQ)), dim3(256), 0, s, q, k8, v8, ks, vs, out, H, P,
-                       T, kv_rep, nocache, nocache, 0, 1, done, done_div);
+    static const int narrow = getenv("MW_PREFILL_NARROW") ? atoi(getenv("MW_PREFILL_NARROW")) : 1;
+    if (P <= 16 && narrow)
+        hipLaunchKernelGGL((prefill_cross_attn_kernel<true, false, 1>), dim3(B * H), dim3(256), 0, s, q, k8, v8, ks, vs, out, H, P, T, kv_rep,
+                           nocache, nocache, 0, 1, done, done_div);
+    else
+        hipLaunchKernelGGL(prefill_cross_attn_kernel<true>, dim3(B * H * ((P + PFQ - 1) / PFQ)), dim3(256), 0, s, q, k8, v8, ks, vs, out, H,
+                           P, T, kv_rep, nocache, nocache, 0, 1, done, done_div);
 }
 
 void launch_prefill_last_rows(const float* x, float* dx, int B, int P, int D, DecState* st, hipStream_t s, int rep, int* src_rows) {
