@@ -90,6 +90,26 @@ def build_gemm_check(force: bool = False, verbose: bool = True) -> str:
     return exe
 
 
+def build_attention_check(force: bool = False, verbose: bool = True) -> str:
+    """tools/attn_bench: the encoder attention (launch_enc_attention) on its own against a naive softmax(QK^T)V, with
+    operands that make the running reference exponent rise at every key tile and with per-element key counts; the GPU
+    tests run it (tests/test_gpu_attention.py).  Links the library's own kernels_enc.o."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "attn_bench.hip")
+    exe = os.path.join(root, "tools", "attn_bench")
+    obj = os.path.join(CSRC, "kernels_enc.o")
+    if force or _stale(exe, [src, obj] + HEADERS):
+        hipcc = _hipcc()
+        tmp = os.path.join(root, "tools", "attn_bench.o")
+        for cmd in ([hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-I", CSRC, "-c", src, "-o", tmp],
+                    [hipcc, f"--offload-arch={ARCH}", tmp, obj, "-o", exe]):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+    return exe
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv))
     print(build_gemm_check(force="--force" in sys.argv))
+    print(build_attention_check(force="--force" in sys.argv))
