@@ -276,7 +276,11 @@ int mw_profile_decode_gemvs(mw_ctx* ctx, int batch, int iters, float* mean_ms_pe
  * "xattn_stream_per_cu" (0..8: resident workgroups per compute unit that walking form is held to; 0 = what its
  * registers allow, the default, and the fastest for an engine that has the GPU to itself.  With several engines on
  * one GPU set 1: the stream keeps 97 % of its rate alone, and the short memory queues it leaves let the
- * latency-bound launches of the other engines through: 149 -> 142 ms per step of the benchmark's arrangement). */
+ * latency-bound launches of the other engines through: 149 -> 142 ms per step of the benchmark's arrangement),
+ * "dec_gemm_fat" (0/1: the projections of a decode group of more than 64 sequences as fewer workgroups with twice
+ * the weight rows each, which halves the times the activations pass through the compute units; default 0, the
+ * faster form for an engine that has the GPU to itself by 4 %.  With several engines on one GPU set 1: 144 -> 140 ms
+ * per step of the benchmark's arrangement). */
 int mw_set_option(mw_ctx* ctx, const char* key, int value);
 
 int mw_synchronize(mw_ctx* ctx);

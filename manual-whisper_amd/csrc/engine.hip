@@ -66,6 +66,7 @@ struct mw_ctx {
     int use_graph = 1, check_every = 4, use_prefill = 1, skip_done = 1;
     int xattn_stream_from = 1024;       // (sequence, head) pairs from which the decode cross-attention walks all keys per workgroup
     int xattn_stream_per_cu = 0;        // resident workgroups per CU that form is held to (0: what its registers allow)
+    int dec_gemm_fat = 0;               // projections of decode groups: 1 = fewer, larger workgroups (engines that share the GPU)
     bool can_end = true;                    // false when the decode options suppress end-of-text everywhere
     const mw_ctx* parent = nullptr;                       // non-null: weights and tables belong to `parent`
 
@@ -438,6 +439,7 @@ extern "C" int mw_fork_cached(mw_ctx* parent, int max_batch, int cache_sequences
     ctx->use_graph = parent->use_graph; ctx->check_every = parent->check_every; ctx->use_prefill = parent->use_prefill;
     ctx->skip_done = parent->skip_done; ctx->xattn_stream_from = parent->xattn_stream_from;
     ctx->xattn_stream_per_cu = parent->xattn_stream_per_cu;
+    ctx->dec_gemm_fat = parent->dec_gemm_fat;
     ctx->parent = parent; ctx->finalized = true;
     // shared, read-only on the hot path
     ctx->conv1_w = parent->conv1_w; ctx->conv1_b = parent->conv1_b; ctx->conv2_w = parent->conv2_w; ctx->conv2_b = parent->conv2_b;
@@ -490,6 +492,10 @@ extern "C" int mw_set_option(mw_ctx* ctx, const char* key, int value) {
         if (value < 0 || value > 8) return fail(ctx, MW_ERR_ARG, "mw_set_option: xattn_stream_per_cu must be in 0..8");
         if (ctx->xattn_stream_per_cu != value) { int r = drop_graphs(ctx); if (r) return r; }
         ctx->xattn_stream_per_cu = value;
+    }
+    else if (!strcmp(key, "dec_gemm_fat")) {
+        if (ctx->dec_gemm_fat != (value != 0)) { int r = drop_graphs(ctx); if (r) return r; }
+        ctx->dec_gemm_fat = value != 0;
     }
     else if (!strcmp(key, "xattn_stream_from")) {
         if (ctx->xattn_stream_from != value) { int r = drop_graphs(ctx); if (r) return r; }
@@ -980,7 +986,7 @@ static void enqueue_layer(mw_ctx* ctx, int li, int B, bool want_logits, const Fi
         p.H = H; p.D = D; p.Tctx = Tc; p.st = ctx->st; p.ln_scratch = ctx->dxn; p.nv = 16;
         p.sk_partial = ctx->skpartial; p.sk_partial_floats = splitk_partial_floats(D);
         p.sk_tickets = ctx->sktickets; p.sk_groups = splitk_groups(D);
-        p.dg_partial = ctx->dgpartial; p.dg_partial_floats = decgemm_partial_floats(D, F, ctx->max_batch); p.dg_groups = splitk_groups(D) * ((ctx->max_batch + 15) / 16);
+        p.dg_partial = ctx->dgpartial; p.dg_partial_floats = decgemm_partial_floats(D, F, ctx->max_batch); p.dg_groups = splitk_groups(D) * ((ctx->max_batch + 15) / 16); p.dg_fat = ctx->dec_gemm_fat;
         return p;
     };
     const DecLayerW& l = ctx->dec[li];

@@ -2205,14 +2205,24 @@ bool launch_gemm_dec_mt(const GemvParams& p, hipStream_t s) {
     if (p.K % KSTEP || p.N % 4 || !p.xin16 || p.ln_g) return false;
     const int nks = p.K / KSTEP;
     const bool wide = p.N >= 2048 || p.K > 2048;
-    const int rt = wide ? 4 : 2;
+    // Row tiles per workgroup, twice as many (8 wide / 4 narrow) beyond 64 sequences when the caller says that other
+    // engines share the GPU (p.dg_fat): every 16 * RT weight rows pull the whole activation matrix through the
+    // L2 -> CU path again, and where the decode groups' K/V streams keep that path busy on every CU the bytes count,
+    // not the number of workgroups (benchmark step 144.0 - 144.4 ms -> 140.7 - 141.3; with the smaller target below
+    // 138.4 - 140.6).  A decode group that has the GPU to itself is 4 % faster with the smaller workgroups (one loop of
+    // 112 sequences: 939 against 994 ms).  MW_DEC_GEMM_RT2X overrides: bit 0 wide, bit 1 narrow.
+    static const int rt_env = getenv("MW_DEC_GEMM_RT2X") ? atoi(getenv("MW_DEC_GEMM_RT2X")) : -1;
+    const bool fat = p.dg_fat && MT > 4;
+    const int rt_scale = rt_env >= 0 ? rt_env : (fat ? 3 : 0);
+    const bool twice = wide ? (rt_scale & 1) : (rt_scale & 2);
+    const int rt = (wide ? 4 : 2) * (twice ? 2 : 1);
     const int groups = (p.N + 16 * rt - 1) / (16 * rt);
     // Workgroups aimed at: about one per CU (240) is what a launch alone on the GPU wants, but every K range writes
     // and re-reads a partial tile of all sequences through memory, and in a run where several decode groups and the
     // encoders share the GPU that traffic costs more than the shorter launch gains: with 120 (three ranges instead of
     // four to six for K = 1280) the benchmark step is 1.5-2 % shorter (156.3-157.1 ms against 158.7-160.2).
     static const int target_env = getenv("MW_DEC_GEMM_WGS") ? atoi(getenv("MW_DEC_GEMM_WGS")) : 0;
-    const int target = target_env > 0 ? target_env : (MT > 4 ? 120 : 240);
+    const int target = target_env > 0 ? target_env : (MT > 4 ? (fat ? 90 : 120) : 240);
     int S = max((nks + KR_MAX - 1) / KR_MAX, min(nks, (target + groups / 2) / groups));
     S = max(1, S);
     int ks_per = (nks + S - 1) / S;
@@ -2225,7 +2235,10 @@ bool launch_gemm_dec_mt(const GemvParams& p, hipStream_t s) {
     q.sk_partial = p.dg_partial;                 // this kernel's own, larger slab; the tickets are shared (always left at zero)
     q.sk_partial_floats = slab; q.sk_groups = groups;                   // extents of one sequence block (group_view)
 #define MW_DG(RT, KR) launch_gemm_dec_t<MT, RT, KR, W8>(q, S, ks_per, s)
-    if (ks_per <= KR_MAX / 2) { if (wide) MW_DG(4, KR_MAX / 2); else MW_DG(2, KR_MAX / 2); }
+    if (twice) {
+        if (ks_per <= KR_MAX / 2) { if (wide) MW_DG(8, KR_MAX / 2); else MW_DG(4, KR_MAX / 2); }
+        else { if (wide) MW_DG(8, KR_MAX); else MW_DG(4, KR_MAX); }
+    } else if (ks_per <= KR_MAX / 2) { if (wide) MW_DG(4, KR_MAX / 2); else MW_DG(2, KR_MAX / 2); }
     else { if (wide) MW_DG(4, KR_MAX); else MW_DG(2, KR_MAX); }
 #undef MW_DG
     return true;
@@ -2239,6 +2252,8 @@ void prepare_gemm_dec_mt() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 4, KR_MAX / 2, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 2, KR_MAX, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 4, KR_MAX, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 8, KR_MAX / 2, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 8, KR_MAX, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
 }
 
 bool launch_gemm_dec(const GemvParams& p, hipStream_t s) {

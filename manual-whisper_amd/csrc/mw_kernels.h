@@ -137,6 +137,7 @@ struct GemvParams {
     // projections of 33..128 sequences (gemm_dec_kernel), optional: partial tiles of its K ranges (dg_partial_floats in
     // all) and the number of row groups the ticket array covers; it shares sk_tickets
     float* dg_partial; long dg_partial_floats; int dg_groups;
+    int dg_fat;               // gemm_dec_kernel: twice the weight rows per workgroup (several engines share the GPU: bytes through the CUs count, not workgroups)
 };
 // floats of partial-tile scratch that cover every projection of a model (d_model D, MLP width F) at up to B sequences
 inline long decgemm_partial_floats(int D, int F, int B = 128) { return (long)(3 * D > F ? 3 * D : F) * 128 * 8 * ((B + 127) / 128); }

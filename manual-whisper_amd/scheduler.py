@@ -69,6 +69,7 @@ class EnginePool:
         if n_engines > 1:       # engines that share the GPU: see GroupedPool
             for e in self.engines:
                 e.set_option("xattn_stream_per_cu", int(os.environ.get("MW_XSTREAM_PER_CU", "1")))
+                e.set_option("dec_gemm_fat", int(os.environ.get("MW_DEC_GEMM_FAT", "1")))
         self._free: "queue.Queue" = queue.Queue()
         for e in self.engines:
             self._free.put(e)
@@ -141,8 +142,11 @@ class GroupedPool:
         # (mw_set_option "xattn_stream_per_cu"); MW_XSTREAM_PER_CU overrides (0 = as many as the registers allow)
         # (a lone decode engine keeps the faster form: only the encoders run beside it, and not for long)
         per_cu = int(os.environ.get("MW_XSTREAM_PER_CU", "1" if n_decoders > 1 else "0"))
+        # and their projections as fewer, larger workgroups ("dec_gemm_fat"; MW_DEC_GEMM_FAT overrides)
+        fat = int(os.environ.get("MW_DEC_GEMM_FAT", "1" if n_decoders > 1 else "0"))
         for e in self.decoders:
             e.set_option("xattn_stream_per_cu", per_cu)
+            e.set_option("dec_gemm_fat", fat)
         self._enc_pool = ThreadPoolExecutor(max_workers=n_encoders)
         self._dec_pool = ThreadPoolExecutor(max_workers=n_decoders)
         self._free_enc: "queue.Queue" = queue.Queue()
