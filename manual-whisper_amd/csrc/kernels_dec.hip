@@ -2201,7 +2201,8 @@ void launch_gemm_dec_t(const GemvParams& p, int S, int ks_per, hipStream_t s) {
 
 template <int MT, bool W8>
 bool launch_gemm_dec_mt(const GemvParams& p, hipStream_t s) {
-    constexpr int KSTEP = W8 ? 64 : 32, KR_MAX = W8 ? 8 : 16;         // 512 columns: 132 KB of LDS at 128 sequences
+    // the longest K range: 512 columns are 132 KB of LDS at 128 sequences; 112 sequences (MT = 7) leave room for 640
+    constexpr int KSTEP = W8 ? 64 : 32, KR_MAX = MT == 7 ? (W8 ? 10 : 20) : (W8 ? 8 : 16);
     if (p.K % KSTEP || p.N % 4 || !p.xin16 || p.ln_g) return false;
     const int nks = p.K / KSTEP;
     const bool wide = p.N >= 2048 || p.K > 2048;
@@ -2215,14 +2216,14 @@ bool launch_gemm_dec_mt(const GemvParams& p, hipStream_t s) {
     const bool fat = p.dg_fat && MT > 4;
     const int rt_scale = rt_env >= 0 ? rt_env : (fat ? 3 : 0);
     const bool twice = wide ? (rt_scale & 1) : (rt_scale & 2);
-    const int rt = (wide ? 4 : 2) * (twice ? 2 : 1);
+    const int rt = MT == 7 ? 8 : (wide ? 4 : 2) * (twice ? 2 : 1);
     const int groups = (p.N + 16 * rt - 1) / (16 * rt);
     // Workgroups aimed at: about one per CU (240) is what a launch alone on the GPU wants, but every K range writes
     // and re-reads a partial tile of all sequences through memory, and in a run where several decode groups and the
     // encoders share the GPU that traffic costs more than the shorter launch gains: with 120 (three ranges instead of
     // four to six for K = 1280) the benchmark step is 1.5-2 % shorter (156.3-157.1 ms against 158.7-160.2).
     static const int target_env = getenv("MW_DEC_GEMM_WGS") ? atoi(getenv("MW_DEC_GEMM_WGS")) : 0;
-    const int target = target_env > 0 ? target_env : (MT > 4 ? (fat ? 90 : 120) : 240);
+    const int target = target_env > 0 ? target_env : MT == 7 ? 20 : (MT > 4 ? (fat ? 90 : 120) : 240);
     int S = max((nks + KR_MAX - 1) / KR_MAX, min(nks, (target + groups / 2) / groups));
     S = max(1, S);
     int ks_per = (nks + S - 1) / S;
@@ -2235,7 +2236,9 @@ bool launch_gemm_dec_mt(const GemvParams& p, hipStream_t s) {
     q.sk_partial = p.dg_partial;                 // this kernel's own, larger slab; the tickets are shared (always left at zero)
     q.sk_partial_floats = slab; q.sk_groups = groups;                   // extents of one sequence block (group_view)
 #define MW_DG(RT, KR) launch_gemm_dec_t<MT, RT, KR, W8>(q, S, ks_per, s)
-    if (twice) {
+    if constexpr (MT == 7) {
+        if (ks_per <= KR_MAX / 2) MW_DG(8, KR_MAX / 2); else MW_DG(8, KR_MAX);
+    } else if (twice) {
         if (ks_per <= KR_MAX / 2) { if (wide) MW_DG(8, KR_MAX / 2); else MW_DG(4, KR_MAX / 2); }
         else { if (wide) MW_DG(8, KR_MAX); else MW_DG(4, KR_MAX); }
     } else if (ks_per <= KR_MAX / 2) { if (wide) MW_DG(4, KR_MAX / 2); else MW_DG(2, KR_MAX / 2); }
@@ -2247,18 +2250,30 @@ bool launch_gemm_dec_mt(const GemvParams& p, hipStream_t s) {
 template <int MT, bool W8>
 void prepare_gemm_dec_mt() {
     constexpr int kDecGemmLds = 144 * 1024;      // the kernel also holds a static word: the whole 160 KiB cannot be dynamic
-    constexpr int KR_MAX = W8 ? 8 : 16;
+    constexpr int KR_MAX = MT == 7 ? (W8 ? 10 : 20) : (W8 ? 8 : 16);
+    static_assert(dec_gemm_lds_bytes<MT, KR_MAX, W8>() <= kDecGemmLds, "the longest K range fits the LDS");
+    if constexpr (MT == 7) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 8, KR_MAX / 2, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 8, KR_MAX, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
+    } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 2, KR_MAX / 2, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 4, KR_MAX / 2, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 2, KR_MAX, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 4, KR_MAX, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 8, KR_MAX / 2, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dec_kernel<MT, 8, KR_MAX, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDecGemmLds);
+    }
 }
 
 bool launch_gemm_dec(const GemvParams& p, hipStream_t s) {
     if (p.B <= 32) return false;
     if (p.B <= 64) return p.W8 ? launch_gemm_dec_mt<4, true>(p, s) : launch_gemm_dec_mt<4, false>(p, s);
+    // up to 112 sequences beside other engines: seven sequence tiles leave LDS for K ranges of 640 columns, i.e. two
+    // ranges instead of three for K = 1280 and 40 % fewer partial tiles through memory (benchmark step 140.3 -> 137.9 ms;
+    // MW_DEC_GEMM_MT7=0 switches it off, 2 keeps it to the wide outputs)
+    static const int mt7 = getenv("MW_DEC_GEMM_MT7") ? atoi(getenv("MW_DEC_GEMM_MT7")) : 1;
+    if (p.B <= 112 && p.dg_fat && mt7 && (mt7 == 1 || p.N >= 2048 || p.K > 2048))
+        return p.W8 ? launch_gemm_dec_mt<7, true>(p, s) : launch_gemm_dec_mt<7, false>(p, s);
     return p.W8 ? launch_gemm_dec_mt<8, true>(p, s) : launch_gemm_dec_mt<8, false>(p, s);
 }
 
@@ -2268,7 +2283,7 @@ int gemv_logits_parts(int N) { return ((N + 15) / 16 + 7) / 8; }
 
 void dec_kernels_prepare() {
     prepare_mt<1>(); prepare_mt<2>();
-    prepare_gemm_dec_mt<4, false>(); prepare_gemm_dec_mt<4, true>(); prepare_gemm_dec_mt<8, false>(); prepare_gemm_dec_mt<8, true>();
+    prepare_gemm_dec_mt<4, false>(); prepare_gemm_dec_mt<4, true>(); prepare_gemm_dec_mt<8, false>(); prepare_gemm_dec_mt<8, true>(); prepare_gemm_dec_mt<7, false>(); prepare_gemm_dec_mt<7, true>();
 }
 
 void launch_gemv(const GemvParams& p0, hipStream_t s) {

@@ -141,11 +141,14 @@ def test_config3_large_v3_batch16_rows_vs_oracle(large):
     assert same == 4           # measured: 4/4 (a row may only part at an oracle near-tie, which these rows do not have)
 
 
-def test_config3_large_v3_decode_group_rows_vs_oracle(large):
+@pytest.mark.parametrize("fat", [1, 0])
+def test_config3_large_v3_decode_group_rows_vs_oracle(large, fat):
     """The benchmark's decode shape: seven encoder passes of 16 chunks written into one decode engine's cache
     (mw_encode_into), one greedy loop over the 112 sequences (the projections then run as gemm_dec_kernel, the
     LayerNorms as launches of their own, the cross-attention as a launch of seven rounds).  4 of the 112 rows x 16
-    sampled tokens against the fp32 oracle, and the group's ids against the same chunks decoded 16 at a time."""
+    sampled tokens against the fp32 oracle, and the group's ids against the same chunks decoded 16 at a time.
+    fat = 1: the projections' form that the pools select when engines share the GPU, as the benchmark's do (option
+    "dec_gemm_fat": 128 weight rows per workgroup and, at 112 sequences, K ranges of 640 columns)."""
     dims, eng, orc = large
     n_new = 16
     opts = synthetic_options(dims, max_new=n_new, suppress_eot=True)
@@ -155,6 +158,7 @@ def test_config3_large_v3_decode_group_rows_vs_oracle(large):
     dec = eng.fork(112)
     try:
         dec.set_decode_options(opts)
+        dec.set_option("dec_gemm_fat", fat)
         for i in range(7):
             eng.encode_into(pcm[16 * i: 16 * i + 16], dec, 16 * i)
         dec.set_encoded(112)

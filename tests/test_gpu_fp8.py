@@ -209,6 +209,7 @@ def test_config5_large_v3_fp8_decode_group_rows_vs_oracle():
         for i in range(7):
             eng.encode_into(pcm[32 * i: 32 * i + 32], dec, 32 * i)
         dec.set_encoded(224)
+        dec.set_option("dec_gemm_fat", 1)          # the projections' form the pools select when engines share the GPU
         ids, lens, logits = dec.decode_greedy(224, want_logits=True)        # logits [n_new][224][vocab]
         assert (lens == n_new).all()
         # a chunk's encoder output does not depend on what shares its pass: the rows' own output, from a pass of their own
@@ -235,6 +236,16 @@ def test_config5_large_v3_fp8_decode_group_rows_vs_oracle():
         for r in np.nonzero((by32 != ids).any(axis=1))[0]:
             n = int(np.nonzero(by32[r] != ids[r])[0][0])
             gap = float(logits[n, r, ids[r, n]] - logits[n, r, by32[r, n]])
+            assert abs(gap) < TIE_GAP, (int(r), n, gap)
+        # the projections' form of an engine that has the GPU to itself: the same sums split differently
+        dec.set_option("dec_gemm_fat", 0)
+        thin, _, thin_logits = dec.decode_greedy(224, want_logits=True)
+        assert float(np.abs(thin_logits[0] - logits[0]).max()) < LOGIT_ATOL / 2
+        apart = np.nonzero((thin != ids).any(axis=1))[0]
+        assert len(apart) <= 9, apart
+        for r in apart:
+            n = int(np.nonzero(thin[r] != ids[r])[0][0])
+            gap = float(logits[n, r, ids[r, n]] - logits[n, r, thin[r, n]])
             assert abs(gap) < TIE_GAP, (int(r), n, gap)
     finally:
         dec.close()

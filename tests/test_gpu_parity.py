@@ -533,6 +533,20 @@ def test_batches_beyond_32_run_as_groups(weight_format):
         eng.encode(100, want_output=False)
         big, _, big_logits = eng.decode_greedy(100, want_logits=True)
         close_enough(big, want[:100], big_logits)
+        # the projections' form for engines that share a GPU ("dec_gemm_fat": twice the weight rows per workgroup,
+        # up to 112 sequences longer K ranges as well): another split of the same sums
+        eng.set_option("dec_gemm_fat", 1)
+        fat, _, fat_logits = eng.decode_greedy(100, want_logits=True)
+        assert np.abs(fat_logits[0] - big_logits[0]).max() < LOGIT_ATOL / 4
+        close_enough(fat, big, fat_logits)
+        eng.logmel(np.concatenate([pcm, pcm[:28]]), want_output=False)     # 128 sequences: the form of 113..128
+        eng.encode(128, want_output=False)
+        fat128, _, fat128_logits = eng.decode_greedy(128, want_logits=True)
+        eng.set_option("dec_gemm_fat", 0)
+        thin128, _, _ = eng.decode_greedy(128, want_logits=True)
+        close_enough(fat128, thin128, fat128_logits)
+        eng.logmel(pcm[:100], want_output=False)
+        eng.encode(100, want_output=False)
         again, _ = eng.transcribe_batch(pcm[:100])
         assert (again == big).all()
         for n in (33, 64):
@@ -553,6 +567,9 @@ def test_batches_beyond_32_run_as_groups(weight_format):
             close_enough(got[100:], tail)
             again, _ = eng.transcribe_batch(pcm2[128:200])                   # the second block on its own
             assert (again == got[128:]).all()
+            wide.set_option("dec_gemm_fat", 1)                               # blocks of 128 in the other form
+            fat200, _ = wide.transcribe_batch(pcm2)
+            close_enough(fat200, got)
         finally:
             wide.close()
         # beam search: 9 recordings x 5 beams = 45 sequences (three groups, the last ragged)
