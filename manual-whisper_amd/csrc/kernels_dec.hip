@@ -659,7 +659,7 @@ __global__ __launch_bounds__(kDecGemmWaves * 64) void gemm_dec_kernel(GemvParams
 // banks of LCH k-steps so a bank's loads are in flight while the other feeds the MFMAs.  Each
 // workgroup also reduces its 128 columns to one (max, lowest index) candidate per sequence under
 // the suppress mask of this position; dec_finalize picks the winner.
-constexpr int LCH = 8;
+constexpr int LCH = 8;      // (logits_wide_kernel's waits name this count)
 template <int MT>
 __global__ __launch_bounds__(512) void logits_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -756,6 +756,138 @@ __global__ __launch_bounds__(512) void logits_kernel(GemvParams p) {
         for (int w = 1; w < 8; ++w) {
             const float ov = cand_v[w * 16 * MT + tid];
             const int oi = cand_i[w * 16 * MT + tid];
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        p.part_val[(long)tid * p.n_parts + part] = best;
+        p.part_idx[(long)tid * p.n_parts + part] = bidx;
+    }
+}
+
+// The same product for decode groups (more than 32 sequences): ONE pass over a part's 128 embedding rows for up to 128
+// sequences, where logits_kernel multiplies them once per 32 sequences and pulls them (and its slice of the
+// activations) through the compute units again every time: 666 MB per token at 112 sequences against 250 MB here.
+// All sequences' activations do not fit the LDS, so K goes by in chunks of 256 columns: two LDS images of
+// [128][256] fp16 (rows 33 pieces of 16 bytes apart, as in gemm_dec_kernel) filled by LDS-DMA one chunk ahead, the
+// weights in two register banks of one chunk each, also one chunk ahead.  More than 128 sequences: blocks of 128, the
+// blocks of a part on consecutive workgroup ids of one XCD (see logits_kernel).
+constexpr int LW_ROWS = 128, LW_PPS = 33, LW_ROUNDS = (LW_ROWS * LW_PPS + 511) / 512;      // 9 rounds of 512 slots
+constexpr int LW_BUF = LW_ROUNDS * 512 * 16;                                                 // 73 728 bytes per image
+constexpr size_t kLogitsWideLds = 2 * (size_t)LW_BUF + 8 * LW_ROWS * 8;
+
+__global__ __launch_bounds__(512) void logits_wide_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int part = blockIdx.x;
+    if (p.B > LW_ROWS) {
+        const int n_groups = (p.B + LW_ROWS - 1) / LW_ROWS;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        part = (idx / n_groups) * 8 + xcd;
+        if (part >= p.n_parts) return;                  // padding of the last slot (the whole workgroup leaves)
+        group_view(p, idx % n_groups, LW_ROWS);
+    }
+    float* cand_v = reinterpret_cast<float*>(smem + 2 * LW_BUF);      // [8][128]
+    int* cand_i = reinterpret_cast<int*>(cand_v + 8 * LW_ROWS);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = (part * 8 + wave) * 16;
+    const int wrow = min(n0 + fr, p.N - 1);
+    const f16* wp = p.W + (long)wrow * p.K + fg * 8;
+    const int nks = p.K >> 5, nchunks = (nks + LCH - 1) / LCH;
+    const int n_live = __builtin_amdgcn_readfirstlane((p.B + 15) / 16);        // sequence tiles that hold a sequence
+    const int sample = p.st->pos - p.st->prompt_len;       // pos was advanced by the final LayerNorm launch
+
+    uint4 wa[LCH], wb[LCH];
+    auto wload = [&](uint4 (&dst)[LCH], int chunk) {
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) dst[c] = load16<kNtLogits>(wp + min(chunk * LCH + c, nks - 1) * 32);
+    };
+    // chunk -> LDS image (chunk & 1): slot = row * 33 + piece; pieces past K repeat the last one (their weights are
+    // zeroed), rows past the last sequence of a live tile repeat the last sequence (never stored), dead tiles stay unfilled
+    auto stage = [&](int chunk) {
+        const int ppr = min(LCH * 4, (p.K - chunk * LCH * 32) / 8);
+        const f16* xbase = p.xin16 + chunk * LCH * 32;
+        char* dst = smem + (chunk & 1) * LW_BUF;
+#pragma unroll
+        for (int j = 0; j < LW_ROUNDS; ++j) {
+            const int first = (j * 8 + wave) * 64;
+            if (first / LW_PPS >= n_live * 16) continue;                  // (wave-uniform)
+            const int slot = first + lane;
+            const int r = slot / LW_PPS, c8 = slot - r * LW_PPS;
+            const f16* src = xbase + (long)min(r, p.B - 1) * p.K + min(c8, ppr - 1) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + (j * 8 + wave) * 1024), 16, 0, 0);
+        }
+    };
+    float4v acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = float4v{0, 0, 0, 0};
+    auto consume = [&](uint4 (&src)[LCH], int chunk) {
+        const char* xs = smem + (chunk & 1) * LW_BUF;
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) {
+            uint4 w = src[c];
+            if (chunk * LCH + c >= nks) w = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t >= n_live) break;
+                const half8 xf = *reinterpret_cast<const half8*>(xs + ((t * 16 + fr) * LW_PPS + c * 4 + fg) * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&w), xf, acc[t], 0, 0, 0);
+            }
+        }
+    };
+    stage(0);
+    wload(wa, 0);
+    if (nchunks > 1) wload(wb, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the compiler does not count the LDS-DMA
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+        // even chunk from bank a, odd chunk from bank b; the image and the bank of chunk + 1 were requested a chunk ago
+        // (the wait before the barrier is for the image; the LCH weight loads issued after it may stay in flight)
+        if (c + 1 < nchunks) stage(c + 1);
+        consume(wa, c);
+        if (c + 2 < nchunks) { wload(wa, c + 2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c + 1 < nchunks) {
+            if (c + 2 < nchunks) stage(c + 2);
+            consume(wb, c + 1);
+            if (c + 3 < nchunks) { wload(wb, c + 3); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    const uint8_t* mask = sample <= 0 ? p.mask_first : p.mask_rest;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (t >= n_live) break;
+        const int m = t * 16 + fr;
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 4 * fg + r;
+            if (n < p.N && m < p.B) {
+                const float v = acc[t][r];
+                if (p.out32) p.out32[(long)m * p.N + n] = v;
+                if (!mask[n] && (v > best || (v == best && n < bidx))) { best = v; bidx = n; }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bidx, o);
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        if (fg == 0) { cand_v[wave * LW_ROWS + m] = best; cand_i[wave * LW_ROWS + m] = bidx; }
+    }
+    __syncthreads();
+    if (tid < LW_ROWS && tid < p.B) {
+        float best = cand_v[tid];
+        int bidx = cand_i[tid];
+        for (int w = 1; w < 8; ++w) {
+            const float ov = cand_v[w * LW_ROWS + tid];
+            const int oi = cand_i[w * LW_ROWS + tid];
             if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
         }
         p.part_val[(long)tid * p.n_parts + part] = best;
@@ -2283,6 +2415,7 @@ int gemv_logits_parts(int N) { return ((N + 15) / 16 + 7) / 8; }
 
 void dec_kernels_prepare() {
     prepare_mt<1>(); prepare_mt<2>();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(logits_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLogitsWideLds);
     prepare_gemm_dec_mt<4, false>(); prepare_gemm_dec_mt<4, true>(); prepare_gemm_dec_mt<8, false>(); prepare_gemm_dec_mt<8, true>(); prepare_gemm_dec_mt<7, false>(); prepare_gemm_dec_mt<7, true>();
 }
 
@@ -2293,6 +2426,12 @@ void launch_gemv(const GemvParams& p0, hipStream_t s) {
     static const int group_mt = getenv("MW_GROUP_MT") ? atoi(getenv("MW_GROUP_MT")) : 2;
     const int mt = p.B <= 16 ? 1 : p.B < group_from ? 2 : group_mt;
     if (p.out_mode == GV_LOGITS) {
+        static const bool wide_off = getenv("MW_LOGITS_WIDE") && !atoi(getenv("MW_LOGITS_WIDE"));
+        if (p.B > 32 && !wide_off && p.K % 32 == 0) {      // decode groups: one pass over the embedding per block of 128 sequences
+            const int parts = gemv_logits_parts(p.N), n_groups = (p.B + LW_ROWS - 1) / LW_ROWS;
+            hipLaunchKernelGGL(logits_wide_kernel, dim3(n_groups > 1 ? (parts + 7) / 8 * 8 * n_groups : parts), dim3(512), kLogitsWideLds, s, p);
+            return;
+        }
         const int parts = gemv_logits_parts(p.N), n_groups = (p.B + 16 * mt - 1) / (16 * mt);
         dim3 grid(n_groups > 1 ? (parts + 7) / 8 * 8 * n_groups : parts);      // several groups: see the id mapping in logits_kernel
         const size_t lds = (size_t)16 * mt * (p.K + 8) * 2 + (size_t)8 * 16 * mt * 8;
