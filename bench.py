@@ -636,13 +636,22 @@ def main(argv=None):
         for i in range(args.group):
             pool.encoders[0].encode_into(pcms[i % len(pcms)], dec, i * batch)
         dec.set_encoded(n_seq)
+        # with the forms an engine takes when it has the GPU to itself (the pool selected those for engines that
+        # share it: one cross-attention workgroup per CU, fewer and larger projection workgroups)
+        shared = {"xattn_stream_per_cu": int(os.environ.get("MW_XSTREAM_PER_CU", "1" if args.decoders > 1 else "0")),
+                  "dec_gemm_fat": int(os.environ.get("MW_DEC_GEMM_FAT", "1" if args.decoders > 1 else "0"))}
+        for k in shared:
+            dec.set_option(k, 0)
+        dec.decode_greedy(n_seq)                # (graph capture)
         dec.decode_greedy(n_seq)
         g_ms = dec.stage_ms()["decode"]
+        for k, v in shared.items():
+            dec.set_option(k, v)
         g_bytes = decode_bytes(dims, n_seq, len(opts.prompt), NEW_TOKENS, 1 if args.weights == "fp8" else 2, args.kv == "fp8")
         g_rate = g_bytes / (g_ms * 1e-3) / 1e9
         group_solo = {"bound": "hbm", "sequences": n_seq, "loop_ms": round(g_ms, 2), "ms_per_16_sequences": round(g_ms * 16 / n_seq, 2),
                       "achieved": round(g_rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g_rate / HBM_PEAK_GBS, 4),
-                      "note": "the greedy loop of one decode group alone on the GPU; in the timed run several groups and the encoders overlap (whole_run)"}
+                      "note": "the greedy loop of one decode group alone on the GPU, in the kernel forms of an engine that is alone (options xattn_stream_per_cu = 0, dec_gemm_fat = 0); in the timed run several groups and the encoders overlap (whole_run)"}
 
     # dominant kernel: decode-time cross-attention, HIP events on the engine's own stream; at the number of
     # sequences it runs on in the timed region (a decode group), and at one step's 16 beside it
