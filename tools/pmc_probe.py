@@ -32,5 +32,8 @@ pcm = synth.make_pcm_np(B, seed=7)
 eng.logmel(pcm, want_output=False)
 eng.encode(B, want_output=False)
 eng.set_option("graph", 0)
+if os.environ.get("MW_SHARED", "0") == "1":      # the kernel forms the pools select for engines that share a GPU
+    eng.set_option("xattn_stream_per_cu", 1)
+    eng.set_option("dec_gemm_fat", 1)
 eng.decode_greedy(B)
 print("done", eng.stage_ms())

@@ -29,5 +29,7 @@ pmc() {  # pmc <tag> : FETCH_SIZE and WRITE_SIZE of tools/pmc_probe.py under the
 }
 pmc f16
 MW_B=112 pmc f16_b112
+MW_B=112 MW_SHARED=1 pmc f16_b112_shared
+st beam5_e3 python3 tools/beam_probe.py 5 48 3 2
 ls $O/keep
 echo PROF_DONE
