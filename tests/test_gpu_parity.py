@@ -584,6 +584,40 @@ def test_batches_beyond_32_run_as_groups(weight_format):
         eng.close()
 
 
+@pytest.mark.parametrize("fat", [0, 1])
+def test_tiny_decode_group_against_passes_of_16(fat):
+    """A decode group at the tiny model's shapes (d_model 384: twelve k-steps, so the logits' second chunk of K and the
+    projections' K ranges are ragged; the full vocabulary, whose last part of 128 rows is ragged): 112 sequences in one
+    greedy loop against the same chunks 16 at a time, in both forms of the projections."""
+    from manual_whisper_amd.engine import Engine
+    dims = mw.get_dims("tiny")
+    eng = Engine(dims, 0, 112)
+    eng.load_weights(synth.make_weights_np(dims, 777))
+    try:
+        opts = synthetic_options(dims, max_new=8)
+        eng.set_decode_options(opts)
+        pcm = synth.make_pcm_np(112, 61)
+        want = np.concatenate([eng.transcribe_batch(pcm[a:a + 16])[0] for a in range(0, 112, 16)])
+        eng.logmel(pcm[:16], want_output=False)
+        eng.encode(16, want_output=False)
+        _, _, first16 = eng.decode_greedy(16, want_logits=True)
+        eng.set_option("dec_gemm_fat", fat)
+        eng.logmel(pcm, want_output=False)
+        eng.encode(112, want_output=False)
+        got, _, logits = eng.decode_greedy(112, want_logits=True)
+        assert np.abs(logits[0][:16] - first16[0]).max() < LOGIT_ATOL / 2
+        apart = np.nonzero((got != want).any(axis=1))[0]
+        assert len(apart) <= 112 // 8, apart
+        for r in apart:
+            pos = int(np.nonzero(got[r] != want[r])[0][0])
+            gap = float(logits[pos, r, got[r, pos]] - logits[pos, r, want[r, pos]])
+            assert abs(gap) < TIE_GAP, (int(r), pos, gap)
+        again, _ = eng.transcribe_batch(pcm)             # the captured graph takes the same route
+        assert (again == got).all()
+    finally:
+        eng.close()
+
+
 def test_model_coalesces_batches_without_changing_ids():
     """load_model(..., coalesce=4): Model.transcribe(batch_size=16) joins four batches per engine pass; the
     segments are those of plain batches of 16."""
