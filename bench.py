@@ -497,8 +497,9 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: whole rounds of the default arrangement (three decode groups of seven steps each = 21 steps), ~6 s timed
+    ap.add_argument("--steps", type=int, default=42)
+    ap.add_argument("--warmup", type=int, default=7)
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--engines", type=int, default=4, help="with --group 1: engines in flight per GPU, each running whole passes (1 = strictly sequential steps)")
     ap.add_argument("--group", type=int, default=7,
