@@ -2404,7 +2404,8 @@ bool launch_gemm_dec(const GemvParams& p, hipStream_t s) {
     // ranges instead of three for K = 1280 and 40 % fewer partial tiles through memory (benchmark step 140.3 -> 137.9 ms;
     // MW_DEC_GEMM_MT7=0 switches it off, 2 keeps it to the wide outputs)
     static const int mt7 = getenv("MW_DEC_GEMM_MT7") ? atoi(getenv("MW_DEC_GEMM_MT7")) : 1;
-    if (p.B <= 112 && p.dg_fat && mt7 && (mt7 == 1 || p.N >= 2048 || p.K > 2048))
+    // (larger groups: blocks of 112 sequences wherever that takes no more blocks than 128 would: 129..224, 257..336, ...)
+    if ((p.B + 111) / 112 == (p.B + 127) / 128 && p.dg_fat && mt7 && (mt7 == 1 || p.N >= 2048 || p.K > 2048))
         return p.W8 ? launch_gemm_dec_mt<7, true>(p, s) : launch_gemm_dec_mt<7, false>(p, s);
     return p.W8 ? launch_gemm_dec_mt<8, true>(p, s) : launch_gemm_dec_mt<8, false>(p, s);
 }
