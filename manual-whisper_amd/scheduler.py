@@ -66,10 +66,11 @@ class EnginePool:
             self.engines = [engine.fork(int(fork_batch), int(fork_cache or fork_batch)) for _ in range(n_engines)]
         else:
             self.engines = [engine] + [engine.fork() for _ in range(n_engines - 1)]
-        if n_engines > 1:       # engines that share the GPU: see GroupedPool
-            for e in self.engines:
-                e.set_option("xattn_stream_per_cu", int(os.environ.get("MW_XSTREAM_PER_CU", "1")))
-                e.set_option("dec_gemm_fat", int(os.environ.get("MW_DEC_GEMM_FAT", "1")))
+        # engines that share the GPU: see GroupedPool (set either way: a fork inherits what its parent was last told)
+        shared = "1" if n_engines > 1 else "0"
+        for e in self.engines:
+            e.set_option("xattn_stream_per_cu", int(os.environ.get("MW_XSTREAM_PER_CU", shared)))
+            e.set_option("dec_gemm_fat", int(os.environ.get("MW_DEC_GEMM_FAT", shared)))
         self._free: "queue.Queue" = queue.Queue()
         for e in self.engines:
             self._free.put(e)
