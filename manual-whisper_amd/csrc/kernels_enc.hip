@@ -134,8 +134,8 @@ __global__ void bcast_rows_kernel(const float* __restrict__ table, float* __rest
 // (column lane&15), 4 keys per 16-key tile: the running max / sum of the online softmax need only
 // the 4 lanes that share a column (v_permlane16_swap + v_permlane32_swap: plain VALU, no LDS round
 // trip).  Those same registers, converted to fp16, are directly the B operand of O^T = V^T P^T
-// (k index = key).  V arrives already transposed ([64][T]) from the QKV GEMM; its tile is staged
-// with the keys permuted in groups of four so that the 8 keys a lane contracts over are contiguous:
+// (k index = key).  V arrives already transposed ([64][T]) from the QKV GEMM; the rows of the K tile are
+// staged in a permuted order (see the kernel) so that the 8 keys a lane contracts over are contiguous in V^T:
 // every V^T fragment is one ds_read_b128, like the K fragments.  Output O^T has the query on the
 // lane again, so the rescale factors are per-lane scalars.
 //
@@ -170,14 +170,13 @@ __device__ __forceinline__ float quad_column_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-// Three workgroups per CU (no spills under the 168 registers that leaves): with a third wave per SIMD the MFMA, exp
-// and LDS phases of different waves overlap; 401 -> 316 us at batch 16.  Counters then show the vector issue port as
-// the busiest unit (about 960 of its cycles per wave and key tile, 256 of them the exponentials, against 512 of the
-// matrix pipe), so the loop is written to issue as few vector instructions as it can:
-//  * K and V^T tiles come through buffer loads: the range check of the descriptor zero-fills keys past the end, the
-//    only a tile offset is added per load, and no lane computes a 64-bit address or a predicate inside the loop.  A V^T
-//    chunk that straddles the end of a row reads on into the next row; those keys carry weight 0 exactly (masked
-//    scores), and the bytes are V values of the same tensor, so finite.
+// Counters show the vector issue port as the busiest unit of this kernel (about 960 of its cycles per wave and key
+// tile in its first form, 256 of them the exponentials, against 512 of the matrix pipe), and on this chip the vector
+// and matrix instructions of the waves of a SIMD add up rather than overlap, so the loop is written to issue as few
+// vector instructions as it can:
+//  * K and V^T tiles go from global memory to LDS by LDS-DMA (see the staging below): no staging registers, no
+//    ds_write, no predicate; with the registers that frees, four workgroups share a CU (two: 401 us at batch 16,
+//    three: 316, four with the rest of this list: 247).
 //  * no per-tile maximum.  The scores come out of the MFMAs relative to the running reference exponent; whether that
 //    reference still holds is read off the lane's own sum of the 16 weights it just formed (needed anyway): a sum
 //    above kSumLimit means some score outgrew the reference, and only then (and for the first tile, which sets the
@@ -187,13 +186,19 @@ __device__ __forceinline__ float quad_column_sum(float v) {
 // keys (and as many queries that matter); its rows still lie T apart.  T below is then the element's own length
 // wherever keys are counted; workgroups whose queries all lie past it have nothing to do.
 constexpr float kSumLimit = 1024.0f;
+// LDS buffers of a workgroup (a K and a V^T tile each).  Two, the next tile requested one ahead, and four workgroups
+// per CU (125 registers): 246.6 us at batch 16; three, two tiles ahead, three workgroups per CU: 256.
+#ifndef MW_ATTN_BUFFERS
+#define MW_ATTN_BUFFERS 2
+#endif
+constexpr int kAttnBuffers = MW_ATTN_BUFFERS;
 typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
 
 template <bool VARLEN>
-__global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+__global__ __launch_bounds__(256, kAttnBuffers == 2 ? 4 : 3) void enc_attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                             const f16* __restrict__ vT, f16* __restrict__ out, int H,
                                                             int Tstride, int Tpad, const int* __restrict__ keys_of) {
-    __shared__ __attribute__((aligned(16))) f16 lds[2][2][AKV * 64];     // [buffer][K | V^T][64 x 64] = 32 KB
+    __shared__ __attribute__((aligned(16))) f16 lds[kAttnBuffers][2][AKV * 64];     // [buffer][K | V^T][64 x 64]: 16 KB each
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     // 1-D grid, XCD-aware: blocks b and b+8 share an XCD, so give each XCD a contiguous run of
@@ -226,39 +231,37 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
         }
     }
 
-    // staging: each thread moves two 16-byte chunks of K and two of V^T per tile.  K rows of this (batch, head) are
-    // one buffer of T rows; V^T is one buffer of 64 rows of Tpad keys.
+    // Staging by LDS-DMA, kAttnBuffers - 1 tiles ahead.  A wave instruction fills
+    // 1 KB = 8 rows of 128 bytes; which 16 bytes of global memory a lane fetches is free, so the row swizzle costs
+    // nothing, and the key order is set by the K side: LDS row rho of the K tile holds key
+    //     pi(rho) = 32 (rho >> 5) + 8 ((rho >> 2) & 3) + 4 ((rho >> 4) & 1) + (rho & 3),
+    // so that the eight scores a lane holds per 32 keys (S^T rows 16 (2s + h) + 4 fg + r) belong to the CONSECUTIVE
+    // keys 32 s + 8 fg + 4 h + r: as fp16 they are directly the B operand of O^T = V^T P^T over an unpermuted V^T
+    // tile.  Nothing is read out of range: K rows past the end repeat the last row (their scores are masked), V^T
+    // chunks past the end repeat the row's last chunk (weight 0 exactly).
     const __amdgpu_buffer_rsrc_t krs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(k + (long)bh * Tstride * 64), 0, T * 128, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(vT + (long)bh * 64 * Tpad), 0, 64 * Tpad * 2, 0x00020000);
-    u32x4e rk[2], rv[2];
-    const int ch = tid & 7;
-    const int kvoff = (tid >> 3) * 128 + ch * 16;                  // byte offsets inside a tile, per thread
-    const int vvoff = (tid >> 3) * Tpad * 2 + ch * 16;
-    const int vrow32 = 32 * Tpad * 2;
-    auto gload = [&](int kv0) {
-        // (the whole offset in the vector operand: that is the one the descriptor's range check covers)
-        rk[0] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff + kv0 * 128, 0, 0);
-        rk[1] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff + (kv0 * 128 + 32 * 128), 0, 0);
-        rv[0] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff + kv0 * 2, 0, 0);
-        rv[1] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff + (kv0 * 2 + vrow32), 0, 0);
-    };
-    // V^T key permutation inside a tile: key 32s + 16h + 4g + r  ->  column 32s + 8g + 4h + r, i.e. the
-    // source chunk c (keys 8c..8c+7: s = c>>2, h = (c>>1)&1, g = 2(c&1), 2(c&1)+1) lands as two
-    // 8-byte pieces in destination chunks 4s + 2(c&1) and 4s + 2(c&1) + 1, at half-offset 4h.
-    const int vdst_chunk = (ch & 4) + 2 * (ch & 1), vdst_off = 4 * ((ch >> 1) & 1);
-    const int row_a = tid >> 3;
-    const int kdst = swz64(row_a, ch), kdst2 = swz64(row_a + 32, ch);
-    const int vdst_a = swz64(row_a, vdst_chunk) + vdst_off, vdst_b = swz64(row_a, vdst_chunk + 1) + vdst_off;
-    const int vdst_c = swz64(row_a + 32, vdst_chunk) + vdst_off, vdst_d = swz64(row_a + 32, vdst_chunk + 1) + vdst_off;
-    auto lstore = [&](int buf) {
-        *reinterpret_cast<u32x4e*>(&lds[buf][0][kdst]) = rk[0];
-        *reinterpret_cast<u32x4e*>(&lds[buf][0][kdst2]) = rk[1];
-        *reinterpret_cast<uint2*>(&lds[buf][1][vdst_a]) = make_uint2(rv[0][0], rv[0][1]);
-        *reinterpret_cast<uint2*>(&lds[buf][1][vdst_b]) = make_uint2(rv[0][2], rv[0][3]);
-        *reinterpret_cast<uint2*>(&lds[buf][1][vdst_c]) = make_uint2(rv[1][0], rv[1][1]);
-        *reinterpret_cast<uint2*>(&lds[buf][1][vdst_d]) = make_uint2(rv[1][2], rv[1][3]);
+    int k_key[2], k_chunk[2], v_row[2], v_chunk[2];       // per lane and DMA instruction: K key inside the tile, byte offsets
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rho = (i * 4 + wave) * 8 + (lane >> 3);           // LDS row this lane fills (K: score row; V^T: head-dim row)
+        const int c = (lane & 7) ^ ((rho >> 1) & 7);                // logical 16-byte chunk that lands at position lane & 7
+        k_key[i] = 32 * (rho >> 5) + 8 * ((rho >> 2) & 3) + 4 * ((rho >> 4) & 1) + (rho & 3);
+        k_chunk[i] = c * 16;
+        v_row[i] = rho * Tpad * 2;
+        v_chunk[i] = c * 8;
+    }
+    auto stage = [&](int kv0, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)&lds[buf][0][(i * 4 + wave) * 512], 16,
+                                                     min(kv0 + k_key[i], T - 1) * 128 + k_chunk[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)&lds[buf][1][(i * 4 + wave) * 512], 16,
+                                                     v_row[i] + min(kv0 + v_chunk[i], Tpad - 8) * 2, 0, 0, 0);
     };
 
     float4v o[4][2];           // [head-dim tile][query tile]: O^T
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (kv0 + i * 16 + 4 * fg + r >= T) { sc[i][0][r] = -1.0e30f; sc[i][1][r] = -1.0e30f; }
+                    if (kv0 + 32 * (i >> 1) + 8 * fg + 4 * (i & 1) + r >= T) { sc[i][0][r] = -1.0e30f; sc[i][1][r] = -1.0e30f; }      // key pi(16 i + 4 fg + r)
         }
     };
     // the tile's maxima become part of the reference (first tile: they ARE the reference, nothing to rescale yet)
@@ -327,12 +330,16 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
     };
 
     const int ntile = (T + AKV - 1) / AKV;
-    gload(0);
-    lstore(0);
+    constexpr int NB = kAttnBuffers, AHEAD = NB - 1;      // tiles requested ahead of the one being worked on
+    stage(0, 0);
+    if (AHEAD == 2 && ntile > 1) { stage(AKV, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }      // (the compiler does not count the LDS-DMA)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int buf = 0;
     for (int it = 0; it < ntile; ++it) {
-        const int buf = it & 1, kv0 = it * AKV;
-        if (it + 1 < ntile) gload(kv0 + AKV);
+        const int kv0 = it * AKV;
+        const bool ahead = it + AHEAD < ntile;
+        if (ahead) stage(kv0 + AHEAD * AKV, buf == 0 ? NB - 1 : buf - 1);      // into the buffer tile it - 1 has left
 
         scores(buf, kv0);
         if (it == 0) raise_reference(true);
@@ -362,8 +369,11 @@ __global__ __launch_bounds__(256, 3) void enc_attention_kernel(const f16* __rest
                 o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][s], o[dt][1], 0, 0, 0);
             }
         }
-        if (it + 1 < ntile) lstore(buf ^ 1);
+        // tile it + 1 (requested an iteration ago, before the four requests of this one) has to be in LDS for everybody
+        if (ahead && AHEAD == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        buf = buf == NB - 1 ? 0 : buf + 1;
     }
 
     // ---- normalise and store: lane holds O[query][16dt + 4fg .. +3]
