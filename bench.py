@@ -42,10 +42,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, spec
 MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X dense fp16 MFMA, spec (no sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix (v_mfma_f32_32x32x2_f32: 256 FLOP/cycle/CU x 256 CUs x 2.4 GHz)
 # HBM bytes per launch of the cross-attention decode kernel at batch 16 from the PMC counters
-# (2 x FETCH_SIZE 60333.3 KB + WRITE_SIZE 530 KB, profiles/round3_pmc_counters_f16.csv); algorithmic bytes are 122.88 MB.
-XATTN_TRAFFIC_BYTES = 2 * 60333.3 * 1024 + 530.0 * 1024
+# (2 x FETCH_SIZE 60336.0 KB + WRITE_SIZE 530 KB, profiles/round3_pmc_counters_f16.csv); algorithmic bytes are 122.88 MB.
+XATTN_TRAFFIC_BYTES = 2 * 60336.0 * 1024 + 530.0 * 1024
 # the same at 112 sequences, the shape of a decode group (algorithmic 860.16 MB), profiles/round3_pmc_counters_f16_b112.csv
-XATTN_TRAFFIC_BYTES_112 = 2 * 420413.0 * 1024 + 280.0 * 1024        # cross_attn_stream_kernel, grid 573440
+XATTN_TRAFFIC_BYTES_112 = 2 * 420413.9 * 1024 + 280.0 * 1024        # cross_attn_stream_kernel, grid 573440
 # the same for cross_attn8_kernel (e4m3 cache; algorithmic 65.28 MB), profiles/round1d_pmc_counters_fp8_kv8.csv
 XATTN8_TRAFFIC_BYTES = 2 * 32439.7 * 1024 + 530.0 * 1024
 BATCH = 16
